@@ -1,0 +1,195 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this package (as the checker / the reported CPU baseline).  Nothing
+under ``srcnn_cpp_amd/`` imports it.
+
+Two families of functions (see the C sources for file:line citations):
+
+* ``conv99 / conv11 / conv55 / conv99x11 / forward_y`` -- the reference's
+  arithmetic (strict multiply-then-add), ``oracle/srcnn_oracle.c``.
+* ``gpuorder_*`` -- a model of the HIP kernels' summation order (FMA chains),
+  ``oracle/srcnn_gpuorder.c``; used only for bitwise regression checks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libsrcnn_oracle.so"
+_lib = None
+
+N_WEIGHTS = 8129
+_f32p = C.POINTER(C.c_float)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def _cpu_has(*flags: str) -> bool:
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+    except OSError:
+        return False
+    line = next((l for l in txt.splitlines() if l.startswith("flags")), "")
+    have = set(line.split())
+    return all(f in have for f in flags)
+
+
+def build(force: bool = False) -> Path:
+    """(Re)build liboracle with oracle/Makefile; generic x86-64 if no AVX2/FMA."""
+    srcs = [_HERE / "srcnn_oracle.c", _HERE / "srcnn_gpuorder.c", _HERE / "Makefile"]
+    stale = (not _LIB_PATH.exists()) or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs)
+    if force or stale:
+        arch = "-mavx2 -mfma" if _cpu_has("avx2", "fma") else ""
+        subprocess.run(["make", "-B", "-C", str(_HERE), f"ARCH={arch}", "all"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _cpu_has("avx2", "fma") and _LIB_PATH.exists():
+            build(force=True)          # prebuilt x86-64-v3 object on an older CPU
+        else:
+            build()
+        _lib = C.CDLL(str(_LIB_PATH))
+        sz, i = C.c_size_t, C.c_int
+        pp = C.POINTER(_f32p)
+        for name in ("srcnn_oracle_conv99",):
+            getattr(_lib, name).argtypes = [_u8p, sz, _f32p, sz, i, i, _f32p, C.c_float]
+        _lib.srcnn_oracle_conv11.argtypes = [pp, sz, _f32p, sz, i, i, _f32p, C.c_float]
+        for name in ("srcnn_oracle_conv55", "srcnn_gpuorder_conv55"):
+            getattr(_lib, name).argtypes = [pp, sz, _u8p, sz, i, i, _f32p, C.c_float, _f32p]
+        for name in ("srcnn_oracle_conv99x11", "srcnn_gpuorder_conv99x11"):
+            getattr(_lib, name).argtypes = [_u8p, sz, pp, sz, i, i, _f32p, _f32p, _f32p, _f32p]
+        for name in ("srcnn_oracle_forward_y", "srcnn_gpuorder_forward_y"):
+            getattr(_lib, name).argtypes = [_u8p, sz, _u8p, sz, i, i, _f32p, _f32p]
+        for name in dir(_lib):
+            pass
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    """OpenMP thread count for subsequent oracle calls (libgomp honours the env
+    only at first use, so go through omp_set_num_threads)."""
+    gomp = C.CDLL("libgomp.so.1")
+    gomp.omp_set_num_threads(int(n))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def _planes(a):
+    """[n][h][w] float32 array -> (array, float** of n plane pointers)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    n = a.shape[0]
+    arr = (_f32p * n)(*[a[k].ctypes.data_as(_f32p) for k in range(n)])
+    return a, arr
+
+
+def split_weights(blob: np.ndarray):
+    """8,129-float blob in convdata.h order -> (w1[64,9,9], b1[64], w2[32,64], b2[32], w3[32,5,5], b3)."""
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    assert blob.size == N_WEIGHTS
+    b1 = blob[0:64]
+    w1 = blob[64:64 + 5184].reshape(64, 9, 9)
+    b2 = blob[5248:5280]
+    w2 = blob[5280:5280 + 2048].reshape(32, 64)
+    b3 = float(blob[7328])
+    w3 = blob[7329:].reshape(32, 5, 5)
+    return w1, b1, w2, b2, w3, b3
+
+
+def conv99(src, kernel, bias):
+    src, ps = _u8(src)
+    h, w = src.shape
+    k, pk = _f32(kernel)
+    dst = np.empty((h, w), np.float32)
+    rc = lib().srcnn_oracle_conv99(ps, w, dst.ctypes.data_as(_f32p), w, w, h, pk, float(bias))
+    assert rc == 0
+    return dst
+
+
+def conv11(planes64, kernel, bias):
+    a, pp = _planes(planes64)
+    _, h, w = a.shape
+    k, pk = _f32(kernel)
+    dst = np.empty((h, w), np.float32)
+    rc = lib().srcnn_oracle_conv11(pp, w, dst.ctypes.data_as(_f32p), w, w, h, pk, float(bias))
+    assert rc == 0
+    return dst
+
+
+def _conv55(fn, planes32, kernel, bias):
+    a, pp = _planes(planes32)
+    _, h, w = a.shape
+    k, pk = _f32(kernel)
+    dst = np.empty((h, w), np.uint8)
+    pre = np.empty((h, w), np.float32)
+    rc = fn(pp, w, dst.ctypes.data_as(_u8p), w, w, h, pk, float(bias), pre.ctypes.data_as(_f32p))
+    assert rc == 0
+    return dst, pre
+
+
+def conv55(planes32, kernel, bias):
+    """-> (u8 plane, f32 pre-clamp plane)"""
+    return _conv55(lib().srcnn_oracle_conv55, planes32, kernel, bias)
+
+
+def gpuorder_conv55(planes32, kernel, bias):
+    return _conv55(lib().srcnn_gpuorder_conv55, planes32, kernel, bias)
+
+
+def _conv99x11(fn, src, k99, b99, k11, b11):
+    src, ps = _u8(src)
+    h, w = src.shape
+    k99, p99 = _f32(k99)
+    b99, pb99 = _f32(b99)
+    k11, p11 = _f32(k11)
+    b11, pb11 = _f32(b11)
+    out = np.empty((32, h, w), np.float32)
+    _, pp = _planes(out)
+    rc = fn(ps, w, pp, w, w, h, p99, pb99, p11, pb11)
+    assert rc == 0
+    return out
+
+
+def conv99x11(src, k99, b99, k11, b11):
+    return _conv99x11(lib().srcnn_oracle_conv99x11, src, k99, b99, k11, b11)
+
+
+def gpuorder_conv99x11(src, k99, b99, k11, b11):
+    return _conv99x11(lib().srcnn_gpuorder_conv99x11, src, k99, b99, k11, b11)
+
+
+def _forward(fn, src, blob):
+    src, ps = _u8(src)
+    h, w = src.shape
+    blob, pw = _f32(blob)
+    assert blob.size == N_WEIGHTS
+    dst = np.empty((h, w), np.uint8)
+    pre = np.empty((h, w), np.float32)
+    rc = fn(ps, w, dst.ctypes.data_as(_u8p), w, w, h, pw, pre.ctypes.data_as(_f32p))
+    assert rc == 0
+    return dst, pre
+
+
+def forward_y(src, blob):
+    """Whole conv path (Convolution99x11 + Convolution55) -> (u8, f32 pre-clamp)."""
+    return _forward(lib().srcnn_oracle_forward_y, src, blob)
+
+
+def gpuorder_forward_y(src, blob):
+    return _forward(lib().srcnn_gpuorder_forward_y, src, blob)

@@ -1,0 +1,207 @@
+/*
+ * srcnn_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's SRCNN Y-channel conv path
+ * (shuwang127/SRCNN_Cpp, src/srcnn.cpp).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the reported CPU baseline -- never as something the product calls.
+ *
+ * PARITY PIN STATUS: LOOSELY PINNED, bit-level "parity unpinned".
+ *   The reference has no tests or golden vectors for this path (src/test.cpp
+ *   belongs to another library and never compares pixels), and its
+ *   src/srcnn.cpp cannot be compiled in this image: it includes OpenCV headers
+ *   (src/srcnn.h:6-9) that are absent, and building it against stand-in
+ *   headers is not allowed.  The only reference-produced artefact is
+ *   Pictures/butterfly-srcnn.png; tests/test_oracle_golden.py pins this
+ *   restatement against its luma (PSNR known-answer, see
+ *   tests/golden/make_butterfly_fixture.py).  Everything below is therefore a
+ *   careful line-by-line restatement, cross-checked by an independent numpy
+ *   float32 restatement (tests/test_oracle_numpy.py), not a proven bit-exact
+ *   copy of a reference binary.
+ *
+ * Arithmetic of record: what the shipped Makefile produces (objects are
+ * compiled with no -O flag and without -ffast-math, Makefile:21-23,43), i.e.
+ * strict IEEE-754 binary32 multiply THEN add, sequential accumulation, no FMA
+ * contraction.  This file must be compiled with -ffp-contract=off and without
+ * -ffast-math (oracle/Makefile does so).
+ *
+ * Data layout: every plane is a row-major array with an explicit row stride
+ * in ELEMENTS; the 32 / 64 feature planes are separate allocations passed as
+ * an array of pointers (the reference's std::vector<cv::Mat>).
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define CONV1_FILTERS 64 /* src/convdata.h:5 */
+#define CONV2_FILTERS 32 /* src/convdata.h:8 */
+
+/* src/srcnn.cpp:77-81 -- clamp c into [a,b] through a 3-entry table. */
+static inline int IntTrim(int a, int b, int c)
+{
+    int buff[3] = {a, c, b};
+    return buff[(int)(c > a) + (int)(c > b)];
+}
+
+/* Border index tables, src/srcnn.cpp:104-113 / 201-210 / 271-280:
+ * tab[i] = clamp(i - radius, 0, n - 1) for i in [0, n + 2*radius). */
+static int *make_clamp_table(int n, int radius)
+{
+    int *tab = (int *)malloc(sizeof(int) * (size_t)(n + 2 * radius));
+    if (!tab) return NULL;
+    for (int i = 0; i < n + 2 * radius; i++) tab[i] = IntTrim(0, n - 1, i - radius);
+    return tab;
+}
+
+/* Convolution99, src/srcnn.cpp:92-140: ONE 9x9 filter, u8 plane -> f32 plane,
+ * + bias, ReLU.  kernel is [9][9] row-major. */
+int srcnn_oracle_conv99(const uint8_t *src, size_t sstride, float *dst, size_t dstride,
+                        int width, int height, const float *kernel, float bias)
+{
+    int *rowf = make_clamp_table(height, 4);
+    int *colf = make_clamp_table(width, 4);
+    if (!rowf || !colf) { free(rowf); free(colf); return -1; }
+
+#pragma omp parallel for
+    for (int row = 0; row < height; row++) {
+        for (int col = 0; col < width; col++) {
+            float temp = 0.f;                                     /* :122 */
+            for (int i = 0; i < 9; i++)
+                for (int j = 0; j < 9; j++) {
+                    /* :128 -- float * (uint8 promoted to int, then float) */
+                    float p = kernel[i * 9 + j] * src[(size_t)rowf[row + i] * sstride + colf[col + j]];
+                    temp += p;
+                }
+            temp += bias;                                         /* :132 */
+            temp = (temp < 0) ? 0 : temp;                         /* :135 */
+            dst[(size_t)row * dstride + col] = temp;              /* :137 */
+        }
+    }
+    free(rowf); free(colf);
+    return 0;
+}
+
+/* Convolution11, src/srcnn.cpp:151-178: ONE output channel of the 1x1 layer,
+ * 64 f32 planes -> 1 f32 plane, + bias, ReLU. */
+int srcnn_oracle_conv11(const float *const *src, size_t sstride, float *dst, size_t dstride,
+                        int width, int height, const float *kernel, float bias)
+{
+#pragma omp parallel for
+    for (int row = 0; row < height; row++) {
+        for (int col = 0; col < width; col++) {
+            float temp = 0.f;                                     /* :164 */
+            for (int i = 0; i < CONV1_FILTERS; i++) {
+                float p = src[i][(size_t)row * sstride + col] * kernel[i];   /* :168 */
+                temp += p;
+            }
+            temp += bias;                                         /* :170 */
+            temp = (temp < 0) ? 0 : temp;                         /* :173 */
+            dst[(size_t)row * dstride + col] = temp;
+        }
+    }
+    return 0;
+}
+
+/* Convolution55, src/srcnn.cpp:189-243: 5x5x32 -> 1, replicate border on the
+ * FEATURE MAP, float product / double 25-term sum / float channel sum, + bias,
+ * truncate to int, clamp 0..255.  kernel is [32][5][5].  preclamp (optional,
+ * may be NULL, same stride as dst) receives the float value after "+= bias"
+ * (:235) and before the truncation -- an oracle-only extra used to state the
+ * floating-point tolerance on the un-quantised value. */
+int srcnn_oracle_conv55(const float *const *src, size_t sstride, uint8_t *dst, size_t dstride,
+                        int width, int height, const float *kernel, float bias,
+                        float *preclamp)
+{
+    int *rowf = make_clamp_table(height, 2);
+    int *colf = make_clamp_table(width, 2);
+    if (!rowf || !colf) { free(rowf); free(colf); return -1; }
+
+#pragma omp parallel for
+    for (int row = 0; row < height; row++) {
+        for (int col = 0; col < width; col++) {
+            float temp = 0;                                       /* :218 */
+            for (int i = 0; i < CONV2_FILTERS; i++) {
+                double temppixel = 0;                             /* :222 */
+                for (int m = 0; m < 5; m++)
+                    for (int n = 0; n < 5; n++) {
+                        /* :227-228 -- float*float product, widened to double on the += */
+                        float p = kernel[(i * 5 + m) * 5 + n] *
+                                  src[i][(size_t)rowf[row + m] * sstride + colf[col + n]];
+                        temppixel += p;
+                    }
+                temp += temppixel;                                /* :232  float = (float)(double(temp)+tp) */
+            }
+            temp += bias;                                         /* :235 */
+            if (preclamp) preclamp[(size_t)row * dstride + col] = temp;
+            temp = IntTrim(0, 255, temp);                         /* :238  float->int truncation, int->float */
+            dst[(size_t)row * dstride + col] = (unsigned char)temp;   /* :240 */
+        }
+    }
+    free(rowf); free(colf);
+    return 0;
+}
+
+/* Convolution99x11, src/srcnn.cpp:254-325: fused layer 1 (9x9x1->64, +bias,
+ * ReLU) and layer 2 (1x1x64->32, +bias, ReLU) per pixel.  kernel99 is
+ * [64][9][9], kernel11 is [32][64].  dst = 32 planes. */
+int srcnn_oracle_conv99x11(const uint8_t *src, size_t sstride, float *const *dst, size_t dstride,
+                           int width, int height,
+                           const float *kernel99, const float *bias99,
+                           const float *kernel11, const float *bias11)
+{
+    int *rowf = make_clamp_table(height, 4);
+    int *colf = make_clamp_table(width, 4);
+    if (!rowf || !colf) { free(rowf); free(colf); return -1; }
+
+#pragma omp parallel for
+    for (int row = 0; row < height; row++) {
+        float temp[CONV1_FILTERS];                                /* :264, private per thread (:283) */
+        for (int col = 0; col < width; col++) {
+            for (int k = 0; k < CONV1_FILTERS; k++) {
+                temp[k] = 0.0;                                    /* :291 */
+                for (int i = 0; i < 9; i++)
+                    for (int j = 0; j < 9; j++) {
+                        float p = kernel99[(k * 9 + i) * 9 + j] *
+                                  src[(size_t)rowf[row + i] * sstride + colf[col + j]];   /* :297 */
+                        temp[k] += p;
+                    }
+                temp[k] += bias99[k];                             /* :301 */
+                temp[k] = (temp[k] < 0) ? 0 : temp[k];            /* :304 */
+            }
+            for (int k = 0; k < CONV2_FILTERS; k++) {
+                float result = 0.0;                               /* :310 */
+                for (int i = 0; i < CONV1_FILTERS; i++) {
+                    float p = temp[i] * kernel11[k * CONV1_FILTERS + i];   /* :314 */
+                    result += p;
+                }
+                result += bias11[k];                              /* :316 */
+                result = (result < 0) ? 0 : result;               /* :319 */
+                dst[k][(size_t)row * dstride + col] = result;     /* :321 */
+            }
+        }
+    }
+    free(rowf); free(colf);
+    return 0;
+}
+
+/* The conv path as the reference's driver runs it (src/srcnn.cpp:602-627):
+ * allocate 32 f32 planes, Convolution99x11, Convolution55.  weights is the
+ * 8,129-float blob in convdata.h declaration order:
+ *   b1[64] | W1[64][9][9] | b2[32] | W2[32][64] | b3[1] | W3[32][5][5]. */
+int srcnn_oracle_forward_y(const uint8_t *src, size_t sstride, uint8_t *dst, size_t dstride,
+                           int width, int height, const float *weights, float *preclamp)
+{
+    const float *b1 = weights, *w1 = b1 + 64, *b2 = w1 + 64 * 81, *w2 = b2 + 32,
+                *b3 = w2 + 32 * 64, *w3 = b3 + 1;
+    size_t plane = (size_t)width * height;
+    float *buf = (float *)malloc(sizeof(float) * plane * CONV2_FILTERS);
+    if (!buf) return -1;
+    float *planes[CONV2_FILTERS];
+    for (int k = 0; k < CONV2_FILTERS; k++) planes[k] = buf + plane * k;
+    int rc = srcnn_oracle_conv99x11(src, sstride, planes, (size_t)width, width, height, w1, b1, w2, b2);
+    if (rc == 0)
+        rc = srcnn_oracle_conv55((const float *const *)planes, (size_t)width, dst, dstride,
+                                 width, height, w3, *b3, preclamp);
+    free(buf);
+    return rc;
+}
