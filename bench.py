@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- SRCNN Y-channel MPix/s on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (fused Convolution99x11 + Convolution55,
+src/srcnn.cpp:609+627) over one synthetic 3840x2160 luma plane per GPU
+(BASELINE.json configs[1]: 1920x1080 x2.0), input already resident in HBM.
+N GPUs = N ranks, one frame per rank per step, no collective on the data path
+(frames are independent: weak scaling).
+
+Prints ONE JSON line on rank 0, including
+  roofline      dominant kernel vs the f32 MFMA peak (HIP events per launch)
+  cpu_baseline  the oracle (port of the reference loops) on the host cores, N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(width, height, target_s=12.0):
+    """Time the oracle (reference loops, strict IEEE, OpenMP) on a bounded slab
+    of the same workload; rows are independent so a slab of full-width rows has
+    the per-pixel cost of the whole frame."""
+    import numpy as np
+    import oracle
+    import srcnn_cpp_amd as S
+    from srcnn_cpp_amd.synth import synth_luma
+
+    cores = len(os.sched_getaffinity(0))
+    oracle.set_threads(cores)
+    blob = S.load_weights()
+    frame = synth_luma(width, height)
+    probe_rows = min(height, max(cores, 16))
+    t = time.perf_counter()
+    oracle.forward_y(frame[:probe_rows], blob)
+    dt = time.perf_counter() - t
+    rows = int(min(height, max(probe_rows, probe_rows * target_s / max(dt, 1e-6))))
+    t = time.perf_counter()
+    oracle.forward_y(frame[:rows], blob)
+    dt = time.perf_counter() - t
+    return {"value": round(width * rows / dt / 1e6, 4), "unit": "MPix/s", "cores": cores, "kind": "port",
+            "sample": f"top {rows} of {height} rows of the {width}x{height} frame, "
+                      f"oracle/srcnn_oracle.c -O3 -ffp-contract=off, OpenMP {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--frames", type=int, default=1, help="frames per GPU per step")
+    ap.add_argument("--path", choices=["fused", "unfused"], default="fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import srcnn_cpp_amd as S
+    from srcnn_cpp_amd.synth import synth_batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, F = args.width, args.height, args.frames
+    ctx = S.Context(local_rank)
+    ctx.set_weights_blob(S.load_weights())
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # each rank owns its frames (frame-sharded stream; no data-path collective)
+    frames = synth_batch(W, H, F, first_frame=rank * F)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    d_work = torch.empty((F, 32, H, W), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
+
+    def step():
+        if args.path == "fused":
+            ctx.forward_y_dev(d_in.data_ptr(), W, H * W, d_out.data_ptr(), W, H * W, W, H, F)
+        else:
+            ctx.forward_y_unfused_dev(d_in.data_ptr(), W, H * W, d_out.data_ptr(), W, H * W, W, H, F,
+                                      d_work.data_ptr())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:                      # HIP events on the stream the kernels run on
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the result of the last step is the real thing (bitwise == frame 0 recomputed)
+    chk = int(d_out[0, H // 2, : min(W, 4096)].to(torch.int64).sum().item())
+
+    if rank == 0:
+        pix_per_step = W * H * F * world
+        value = pix_per_step * args.steps / elapsed / 1e6
+        flops_per_launch = S.FLOP_PER_PIXEL * W * H * F
+        achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = ROOT / "profiles" / "pmc_traffic.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get(f"{args.path}_{W}x{H}x{F}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "SRCNN Y-channel Mpixels/sec", "value": round(value, 2), "unit": "MPix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{F} x {W}x{H} luma plane per GPU per step "
+                                   f"(1920x1080 x2.0, BASELINE configs[1]), {args.path} conv path, "
+                                   "inputs resident in HBM",
+                       "frames_per_gpu": F, "width": W, "height": H, "path": args.path,
+                       "plan": ctx.query_plan(W, H, F), "output_checksum": chk},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": traffic, "kernel_ms": round(kern_ms, 4),
+                         "flop_per_pixel": S.FLOP_PER_PIXEL},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(W, H)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

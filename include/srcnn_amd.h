@@ -1,0 +1,170 @@
+/*
+ * srcnn_amd.h -- C ABI of the MI355X (gfx950) SRCNN Y-channel conv path.
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (shuwang127/SRCNN_Cpp) has no FFI layer: its boundary is four free C++
+ * functions declared at src/srcnn.cpp:60-73 and called from the pipeline
+ * driver at src/srcnn.cpp:609 and :627.  Each entry point below names the
+ * reference function it replaces; include/srcnn_amd.hpp restates the four
+ * reference prototypes on top of this ABI.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers and sizes only; no C++/HIP/torch types cross the ABI;
+ *   - every plane is row-major with an explicit row stride in ELEMENTS
+ *     (cv::Mat::step1()); feature maps are arrays of per-plane pointers, the
+ *     reference's std::vector<cv::Mat>;
+ *   - the caller owns and pre-allocates every output (src/srcnn.cpp:602-607,
+ *     :625-626); the library owns device memory inside the context;
+ *   - weights use the reference's layouts (src/convdata.h:10-16):
+ *     kernel99 [64][9][9], bias99 [64], kernel11 [32][64], bias11 [32],
+ *     kernel55 [32][5][5], bias55 scalar;
+ *   - return 0 on success, a negative SRCNN_ERR_* otherwise (the reference
+ *     functions return void and are unchecked); never throws;
+ *   - a context is bound to one GPU and one HIP stream and is NOT internally
+ *     locked: use one context per host thread (the reference calls the path
+ *     from a single worker thread, src/srcnn.cpp:720).
+ *   - there is NO CPU fallback: without a usable gfx950 device srcnn_create
+ *     fails with SRCNN_ERR_NODEVICE.
+ */
+#ifndef SRCNN_AMD_H
+#define SRCNN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRCNN_CONV1_FILTERS 64 /* src/convdata.h:5 */
+#define SRCNN_CONV2_FILTERS 32 /* src/convdata.h:8 */
+
+enum {
+    SRCNN_OK = 0,
+    SRCNN_ERR_INVALID = -1,  /* null pointer, non-positive size, stride < width ... */
+    SRCNN_ERR_HIP = -2,      /* a HIP runtime call failed; see srcnn_last_error()     */
+    SRCNN_ERR_NOMEM = -3,    /* device or host allocation failed                      */
+    SRCNN_ERR_NODEVICE = -4, /* no gfx950 device / device index out of range          */
+    SRCNN_ERR_STATE = -5     /* e.g. forward called before srcnn_set_weights          */
+};
+
+/* Arithmetic mode of the layer-1/2/3 kernels.
+ *   SRCNN_MODE_MFMA  (default) v_mfma_f32_32x32x2_f32 chains: float32, fused
+ *                    multiply-add, reference summation order for layers 1-2,
+ *                    tap-partial order for layer 3; matches the reference
+ *                    within the tolerance stated in DESIGN.md.
+ *   SRCNN_MODE_EXACT reference arithmetic reproduced exactly on the vector
+ *                    ALU (rounded multiply then rounded add, double 25-term
+ *                    sums in layer 3): bit-identical to the reference CPU
+ *                    path, roughly 4x slower. */
+enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1 };
+
+typedef struct srcnn_ctx srcnn_ctx;
+
+/* ---- context -------------------------------------------------------------- */
+
+/* Create a context on HIP device `device` with its own non-blocking stream. */
+int srcnn_create(srcnn_ctx **out, int device);
+void srcnn_destroy(srcnn_ctx *ctx);
+/* Human-readable text for the last error on this context (never NULL). */
+const char *srcnn_last_error(const srcnn_ctx *ctx);
+/* ABI version, bumped on incompatible change. */
+int srcnn_abi_version(void);
+int srcnn_set_mode(srcnn_ctx *ctx, int mode);
+int srcnn_get_mode(const srcnn_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*) for all work of this context,
+ * e.g. the caller's framework stream; NULL restores the context's own stream. */
+int srcnn_set_stream(srcnn_ctx *ctx, void *hip_stream);
+/* Block until all work queued by this context has finished. */
+int srcnn_synchronize(srcnn_ctx *ctx);
+
+/* ---- the reference call surface, host buffers ----------------------------- */
+
+/* Replaces Convolution99 (src/srcnn.cpp:92-140): ONE 9x9 filter over a u8
+ * plane with replicate border, + bias, ReLU -> f32 plane.  Bit-exact. */
+int srcnn_conv99(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
+                 float *dst, size_t dst_stride, int width, int height,
+                 const float *kernel /*[9][9]*/, float bias);
+
+/* Replaces Convolution11 (src/srcnn.cpp:151-178): ONE output channel of the
+ * 1x1 layer, 64 f32 planes -> f32 plane, + bias, ReLU.  Bit-exact. */
+int srcnn_conv11(srcnn_ctx *ctx, const float *const *src /*[64]*/, size_t src_stride,
+                 float *dst, size_t dst_stride, int width, int height,
+                 const float *kernel /*[64]*/, float bias);
+
+/* Replaces Convolution55 (src/srcnn.cpp:189-243): 5x5x32 -> 1 with replicate
+ * border on the feature map, + bias, truncate, clamp 0..255 -> u8 plane. */
+int srcnn_conv55(srcnn_ctx *ctx, const float *const *src /*[32]*/, size_t src_stride,
+                 uint8_t *dst, size_t dst_stride, int width, int height,
+                 const float *kernel /*[32][5][5]*/, float bias);
+
+/* Replaces Convolution99x11 (src/srcnn.cpp:254-325): fused 9x9x1->64 (+bias,
+ * ReLU) and 1x1x64->32 (+bias, ReLU); u8 plane -> 32 f32 planes. */
+int srcnn_conv99x11(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
+                    float *const *dst /*[32]*/, size_t dst_stride, int width, int height,
+                    const float *kernel99 /*[64][9][9]*/, const float *bias99 /*[64]*/,
+                    const float *kernel11 /*[32][64]*/, const float *bias11 /*[32]*/);
+
+/* ---- whole path: what src/srcnn.cpp:602-627 does with the above ------------ */
+
+/* Upload the model once (any later call may replace it). */
+int srcnn_set_weights(srcnn_ctx *ctx,
+                      const float *kernel99, const float *bias99,
+                      const float *kernel11, const float *bias11,
+                      const float *kernel55, float bias55);
+
+/* Convolution99x11 + Convolution55 in ONE fused kernel: u8 luma in, u8 luma
+ * out, the 32-channel map never leaves the CU.  preclamp (optional, may be
+ * NULL) receives the float value before truncation/clamp. */
+int srcnn_forward_y(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
+                    uint8_t *dst, size_t dst_stride, int width, int height,
+                    float *preclamp, size_t preclamp_stride);
+
+/* ---- device-resident entry points (pointers are DEVICE memory) ------------- *
+ * Asynchronous on the context's stream; the caller synchronises.               */
+
+/* n_frames independent planes, frame f at base + f*frame_pitch (elements). */
+int srcnn_forward_y_dev(srcnn_ctx *ctx,
+                        const uint8_t *d_src, size_t src_stride, size_t src_frame_pitch,
+                        uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch,
+                        int width, int height, int n_frames,
+                        float *d_preclamp /*may be NULL; dst strides*/);
+
+/* Row stripe of ONE width x height image (multi-GPU row striping): produce
+ * output rows [row_begin,row_end).  d_src points at image row src_row0 and
+ * must hold rows [max(0,row_begin-6), min(height,row_end+6)) -- the 13x13
+ * receptive field -- d_dst points at image row dst_row0.  Image-edge rows are
+ * replicated as in the reference, stripe-edge rows come from the halo. */
+int srcnn_forward_y_rows_dev(srcnn_ctx *ctx,
+                             const uint8_t *d_src, size_t src_stride, int src_row0,
+                             uint8_t *d_dst, size_t dst_stride, int dst_row0,
+                             int width, int height, int row_begin, int row_end);
+
+/* Materialising variant of the whole path (layer-1/2 kernel writes the 32
+ * planar f32 maps to HBM, layer-3 kernel reads them back), n_frames planes.
+ * d_work must hold n_frames*32*height*width floats. */
+int srcnn_forward_y_unfused_dev(srcnn_ctx *ctx,
+                                const uint8_t *d_src, size_t src_stride, size_t src_frame_pitch,
+                                uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch,
+                                int width, int height, int n_frames, float *d_work);
+
+/* Layer kernels on device memory.  d_planes is ONE allocation holding 32
+ * planes, plane k at d_planes + k*plane_pitch (elements). */
+int srcnn_conv99x11_dev(srcnn_ctx *ctx, const uint8_t *d_src, size_t src_stride,
+                        float *d_planes, size_t plane_stride, size_t plane_pitch,
+                        int width, int height);
+int srcnn_conv55_dev(srcnn_ctx *ctx, const float *d_planes, size_t plane_stride, size_t plane_pitch,
+                     uint8_t *d_dst, size_t dst_stride, int width, int height,
+                     float *d_preclamp /*may be NULL*/);
+
+/* ---- introspection for the bench / tests ---------------------------------- */
+
+/* Launch geometry the fused kernel would use for (width,height,n_frames):
+ * out[0]=workgroups, out[1]=rows per segment, out[2]=strips, out[3]=segments,
+ * out[4]=LDS bytes per workgroup, out[5]=threads per workgroup. */
+int srcnn_query_plan(srcnn_ctx *ctx, int width, int height, int n_frames, int out[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCNN_AMD_H */

@@ -1,0 +1,162 @@
+// srcnn_amd.hpp -- C++ host-side mirror of the reference's call surface over
+// the C ABI (srcnn_amd.h).  Header-only.
+//
+// The four free functions below have the names, argument order and argument
+// meaning of the reference's prototypes at src/srcnn.cpp:60-73:
+//
+//   void Convolution99   (Mat& src, Mat& dst, const float kernel[9][9], float bias);
+//   void Convolution11   (vector<Mat>& src, Mat& dst, const float kernel[64], float bias);
+//   void Convolution55   (vector<Mat>& src, Mat& dst, const float kernel[32][5][5], float bias);
+//   void Convolution99x11(Mat& src, vector<Mat>& dst, const float kernel99[64][9][9],
+//                         const float bias99[64], const float kernel11[32][64], const float bias11[32]);
+//
+// They are templates over the matrix type, which only has to look like the
+// part of cv::Mat the reference uses: `.rows`, `.cols`, `.data` (first byte)
+// and `.step` convertible to size_t (row stride in BYTES).  cv::Mat satisfies
+// that as is, so with OpenCV present a reference build only has to include
+// this header instead of defining its own loops;
+// srcnn::Plane<T> is a dependency-free stand-in for hosts without OpenCV.
+//
+// Like the reference functions they return void and write dst in place
+// (src/srcnn.cpp:137,175,240,321); a failure of the GPU path throws
+// srcnn::Error -- there is no CPU fallback.
+#ifndef SRCNN_AMD_HPP
+#define SRCNN_AMD_HPP
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "srcnn_amd.h"
+
+namespace srcnn {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+// Minimal row-major plane with cv::Mat's field names.
+template <class T>
+struct Plane {
+    int rows = 0, cols = 0;
+    std::size_t step = 0;            // bytes per row
+    unsigned char *data = nullptr;
+    std::vector<T> storage;
+    Plane() = default;
+    Plane(int cols_, int rows_) { create(cols_, rows_); }
+    void create(int cols_, int rows_)
+    {
+        rows = rows_;
+        cols = cols_;
+        storage.assign(static_cast<std::size_t>(rows) * cols, T());
+        step = sizeof(T) * static_cast<std::size_t>(cols);
+        data = reinterpret_cast<unsigned char *>(storage.data());
+    }
+    T &at(int r, int c) { return storage[static_cast<std::size_t>(r) * cols + c]; }
+    const T &at(int r, int c) const { return storage[static_cast<std::size_t>(r) * cols + c]; }
+    bool empty() const { return storage.empty(); }
+};
+
+// One lazily created context per host thread (the reference calls the path
+// from a single worker thread, src/srcnn.cpp:720).
+class Session {
+public:
+    explicit Session(int device = 0)
+    {
+        int rc = srcnn_create(&ctx_, device);
+        if (rc != SRCNN_OK) throw Error(rc, "srcnn_create failed (a gfx950 GPU is required)");
+    }
+    ~Session() { srcnn_destroy(ctx_); }
+    Session(const Session &) = delete;
+    Session &operator=(const Session &) = delete;
+    srcnn_ctx *get() const { return ctx_; }
+    void check(int rc) const
+    {
+        if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(ctx_));
+    }
+    static Session &thread_default()
+    {
+        thread_local Session s(0);
+        return s;
+    }
+
+private:
+    srcnn_ctx *ctx_ = nullptr;
+};
+
+namespace detail {
+template <class T, class M>
+inline T *ptr(M &m) { return reinterpret_cast<T *>(m.data); }
+template <class T, class M>
+inline std::size_t stride(const M &m) { return static_cast<std::size_t>(m.step) / sizeof(T); }
+}  // namespace detail
+
+// ---- the reference call surface -------------------------------------------
+
+template <class MatU8, class MatF32>
+inline void Convolution99(MatU8 &src, MatF32 &dst, const float kernel[9][9], float bias)
+{
+    Session &s = Session::thread_default();
+    s.check(srcnn_conv99(s.get(), detail::ptr<const std::uint8_t>(src), detail::stride<std::uint8_t>(src),
+                         detail::ptr<float>(dst), detail::stride<float>(dst), dst.cols, dst.rows,
+                         &kernel[0][0], bias));                 // dims from dst: src/srcnn.cpp:94-95
+}
+
+template <class MatF32>
+inline void Convolution11(std::vector<MatF32> &src, MatF32 &dst, const float kernel[SRCNN_CONV1_FILTERS],
+                          float bias)
+{
+    if (src.size() != SRCNN_CONV1_FILTERS) throw Error(SRCNN_ERR_INVALID, "Convolution11: need 64 planes");
+    const float *planes[SRCNN_CONV1_FILTERS];
+    for (int k = 0; k < SRCNN_CONV1_FILTERS; ++k) planes[k] = detail::ptr<const float>(src[k]);
+    Session &s = Session::thread_default();
+    s.check(srcnn_conv11(s.get(), planes, detail::stride<float>(src[0]), detail::ptr<float>(dst),
+                         detail::stride<float>(dst), dst.cols, dst.rows, kernel, bias));
+}
+
+template <class MatF32, class MatU8>
+inline void Convolution55(std::vector<MatF32> &src, MatU8 &dst, const float kernel[32][5][5], float bias)
+{
+    if (src.size() != SRCNN_CONV2_FILTERS) throw Error(SRCNN_ERR_INVALID, "Convolution55: need 32 planes");
+    const float *planes[SRCNN_CONV2_FILTERS];
+    for (int k = 0; k < SRCNN_CONV2_FILTERS; ++k) planes[k] = detail::ptr<const float>(src[k]);
+    Session &s = Session::thread_default();
+    s.check(srcnn_conv55(s.get(), planes, detail::stride<float>(src[0]), detail::ptr<std::uint8_t>(dst),
+                         detail::stride<std::uint8_t>(dst), dst.cols, dst.rows, &kernel[0][0][0], bias));
+}
+
+template <class MatU8, class MatF32>
+inline void Convolution99x11(MatU8 &src, std::vector<MatF32> &dst,
+                             const float kernel99[SRCNN_CONV1_FILTERS][9][9],
+                             const float bias99[SRCNN_CONV1_FILTERS],
+                             const float kernel11[SRCNN_CONV2_FILTERS][SRCNN_CONV1_FILTERS],
+                             const float bias11[SRCNN_CONV2_FILTERS])
+{
+    if (dst.size() != SRCNN_CONV2_FILTERS) throw Error(SRCNN_ERR_INVALID, "Convolution99x11: need 32 planes");
+    float *planes[SRCNN_CONV2_FILTERS];
+    for (int k = 0; k < SRCNN_CONV2_FILTERS; ++k) planes[k] = detail::ptr<float>(dst[k]);
+    Session &s = Session::thread_default();
+    s.check(srcnn_conv99x11(s.get(), detail::ptr<const std::uint8_t>(src), detail::stride<std::uint8_t>(src),
+                            planes, detail::stride<float>(dst[0]), src.cols, src.rows,   // dims from src: :262-263
+                            &kernel99[0][0][0], bias99, &kernel11[0][0], bias11));
+}
+
+// The whole conv path of src/srcnn.cpp:602-627 in one fused kernel.
+template <class MatU8>
+inline void ForwardY(MatU8 &src, MatU8 &dst, const float kernel99[64][9][9], const float bias99[64],
+                     const float kernel11[32][64], const float bias11[32], const float kernel55[32][5][5],
+                     float bias55)
+{
+    Session &s = Session::thread_default();
+    s.check(srcnn_set_weights(s.get(), &kernel99[0][0][0], bias99, &kernel11[0][0], bias11,
+                              &kernel55[0][0][0], bias55));
+    s.check(srcnn_forward_y(s.get(), detail::ptr<const std::uint8_t>(src), detail::stride<std::uint8_t>(src),
+                            detail::ptr<std::uint8_t>(dst), detail::stride<std::uint8_t>(dst), src.cols,
+                            src.rows, nullptr, 0));
+}
+
+}  // namespace srcnn
+#endif  // SRCNN_AMD_HPP

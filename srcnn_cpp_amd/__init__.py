@@ -1,0 +1,320 @@
+"""srcnn_cpp_amd -- MI355X-native SRCNN Y-channel conv path.
+
+This package is a thin ctypes binding of the C ABI in ``include/srcnn_amd.h``
+(``libsrcnn_amd.so``, hand-written HIP for gfx950) plus a Python restatement of
+the reference's call surface for tests and the bench:
+
+    Convolution99(src, dst, kernel, bias)                  src/srcnn.cpp:92
+    Convolution11(src, dst, kernel, bias)                  src/srcnn.cpp:151
+    Convolution55(src, dst, kernel, bias)                  src/srcnn.cpp:189
+    Convolution99x11(src, dst, k99, b99, k11, b11)         src/srcnn.cpp:254
+
+with the reference's argument meaning: ``dst`` is pre-allocated by the caller
+and written in place, planes are 2-D numpy arrays (any row stride), feature
+maps are sequences of 32 / 64 planes.  The C++ host-side mirror a reference
+maintainer would use is ``include/srcnn_amd.hpp``.
+
+There is NO CPU fallback: importing works anywhere, but every compute call
+needs the HIP library and a gfx950 device and raises ``SrcnnError`` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+__all__ = [
+    "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
+    "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
+    "MODE_MFMA", "MODE_EXACT", "FLOP_PER_PIXEL",
+]
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "libsrcnn_amd.so"
+_WEIGHTS_PATH = _PKG / "data" / "srcnn915_weights.f32"
+
+MODE_MFMA = 0
+MODE_EXACT = 1
+N_WEIGHTS = 8129
+# 2 x (64*81 + 32*64 + 32*25) MAC per output pixel
+FLOP_PER_PIXEL = 16064
+
+_ERR = {-1: "invalid argument", -2: "HIP runtime error", -3: "out of memory",
+        -4: "no gfx950 device", -5: "bad state"}
+
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_f32pp = C.POINTER(_f32p)
+_lib = None
+
+
+class SrcnnError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        self.code = code
+        super().__init__(f"srcnn error {code} ({_ERR.get(code, '?')}): {msg}")
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsrcnn_amd.so; fails loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise SrcnnError(-4, f"{_LIB_PATH} not built: run `python -m srcnn_cpp_amd.build` "
+                             "(there is no CPU fallback)")
+    lib = C.CDLL(str(_LIB_PATH))
+    sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
+    sigs = {
+        "srcnn_abi_version": ([], i),
+        "srcnn_create": ([C.POINTER(vp), i], i),
+        "srcnn_destroy": ([vp], None),
+        "srcnn_last_error": ([vp], C.c_char_p),
+        "srcnn_set_mode": ([vp, i], i),
+        "srcnn_get_mode": ([vp], i),
+        "srcnn_set_stream": ([vp, vp], i),
+        "srcnn_synchronize": ([vp], i),
+        "srcnn_conv99": ([vp, _u8p, sz, _f32p, sz, i, i, _f32p, C.c_float], i),
+        "srcnn_conv11": ([vp, _f32pp, sz, _f32p, sz, i, i, _f32p, C.c_float], i),
+        "srcnn_conv55": ([vp, _f32pp, sz, _u8p, sz, i, i, _f32p, C.c_float], i),
+        "srcnn_conv99x11": ([vp, _u8p, sz, _f32pp, sz, i, i, _f32p, _f32p, _f32p, _f32p], i),
+        "srcnn_set_weights": ([vp, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float], i),
+        "srcnn_forward_y": ([vp, _u8p, sz, _u8p, sz, i, i, _f32p, sz], i),
+        "srcnn_forward_y_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
+        "srcnn_forward_y_rows_dev": ([vp, vp, sz, i, vp, sz, i, i, i, i, i], i),
+        "srcnn_forward_y_unfused_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
+        "srcnn_conv99x11_dev": ([vp, vp, sz, vp, sz, sz, i, i], i),
+        "srcnn_conv55_dev": ([vp, vp, sz, sz, vp, sz, i, i, vp], i),
+        "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
+    }
+    for name, (args, res) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+        fn.argtypes = args
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+ABI_SYMBOLS = (
+    "srcnn_abi_version", "srcnn_create", "srcnn_destroy", "srcnn_last_error", "srcnn_set_mode",
+    "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_conv99", "srcnn_conv11",
+    "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_dev",
+    "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
+    "srcnn_conv55_dev", "srcnn_query_plan",
+)
+
+
+def load_weights(path: Optional[Path] = None) -> np.ndarray:
+    """The SRCNN 9-1-5 parameters as an 8,129-float blob in convdata.h order
+    (b1|W1|b2|W2|b3|W3; provenance: oracle/dump_weights.c)."""
+    blob = np.fromfile(str(path or _WEIGHTS_PATH), dtype="<f4")
+    if blob.size != N_WEIGHTS:
+        raise ValueError(f"weight blob has {blob.size} floats, expected {N_WEIGHTS}")
+    return blob
+
+
+def split_weights(blob: np.ndarray):
+    """blob -> (w1[64,9,9], b1[64], w2[32,64], b2[32], w3[32,5,5], b3)."""
+    blob = np.ascontiguousarray(blob, dtype=np.float32)
+    return (blob[64:5248].reshape(64, 9, 9), blob[0:64], blob[5280:7328].reshape(32, 64),
+            blob[5248:5280], blob[7329:8129].reshape(32, 5, 5), float(blob[7328]))
+
+
+def _plane(a, dtype, name, writable=False):
+    if not isinstance(a, np.ndarray) or a.ndim != 2 or a.dtype != dtype:
+        raise TypeError(f"{name}: expected a 2-D numpy array of {np.dtype(dtype).name}")
+    if a.strides[1] != a.itemsize or a.strides[0] % a.itemsize or a.strides[0] < a.shape[1] * a.itemsize:
+        raise ValueError(f"{name}: rows must be contiguous (row stride may be padded)")
+    if writable and not a.flags.writeable:
+        raise ValueError(f"{name}: output plane is read-only")
+    return a, a.strides[0] // a.itemsize
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _ptr_array(planes, n, name, writable=False):
+    if len(planes) != n:
+        raise ValueError(f"{name}: expected {n} planes, got {len(planes)}")
+    stride = None
+    shape = None
+    for k, p in enumerate(planes):
+        _, s = _plane(p, np.float32, f"{name}[{k}]", writable)
+        if stride is None:
+            stride, shape = s, p.shape
+        elif s != stride or p.shape != shape:
+            raise ValueError(f"{name}: all planes must share shape and row stride")
+    arr = (_f32p * n)(*[_fp(p) for p in planes])
+    return arr, stride, shape
+
+
+def _wt(a, n, name):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.size != n:
+        raise ValueError(f"{name}: expected {n} floats, got {a.size}")
+    return a
+
+
+class Context:
+    """One GPU + one stream (``srcnn_ctx``).  Not thread-safe; one per thread."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.srcnn_create(C.byref(h), int(device))
+        if rc != 0:
+            raise SrcnnError(rc, f"srcnn_create(device={device}) -- a gfx950 GPU is required, "
+                                 "there is no CPU fallback")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.srcnn_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SrcnnError(rc, self._lib.srcnn_last_error(self._h).decode())
+
+    # -- configuration ------------------------------------------------------
+    def set_mode(self, mode: int):
+        self._check(self._lib.srcnn_set_mode(self._h, int(mode)))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.srcnn_set_stream(self._h, C.c_void_p(int(hip_stream) or None)))
+
+    def synchronize(self):
+        self._check(self._lib.srcnn_synchronize(self._h))
+
+    def set_weights(self, w1, b1, w2, b2, w3, b3):
+        w1, b1 = _wt(w1, 5184, "kernel99"), _wt(b1, 64, "bias99")
+        w2, b2 = _wt(w2, 2048, "kernel11"), _wt(b2, 32, "bias11")
+        w3 = _wt(w3, 800, "kernel55")
+        self._check(self._lib.srcnn_set_weights(self._h, _fp(w1), _fp(b1), _fp(w2), _fp(b2), _fp(w3), float(b3)))
+
+    def set_weights_blob(self, blob):
+        self.set_weights(*split_weights(blob))
+
+    def query_plan(self, width, height, n_frames=1):
+        out = (C.c_int * 6)()
+        self._check(self._lib.srcnn_query_plan(self._h, width, height, n_frames, C.byref(out)))
+        return dict(workgroups=out[0], seg_rows=out[1], strips=out[2], segments=out[3],
+                    lds_bytes=out[4], threads=out[5])
+
+    # -- the reference call surface (host buffers, dst written in place) ----
+    def conv99(self, src, dst, kernel, bias):
+        src, ss = _plane(src, np.uint8, "src")
+        dst, ds = _plane(dst, np.float32, "dst", True)
+        k = _wt(kernel, 81, "kernel")
+        h, w = dst.shape                       # dims come from dst: src/srcnn.cpp:94-95
+        self._check(self._lib.srcnn_conv99(self._h, src.ctypes.data_as(_u8p), ss, _fp(dst), ds, w, h,
+                                           _fp(k), float(bias)))
+
+    def conv11(self, src, dst, kernel, bias):
+        arr, ss, _ = _ptr_array(src, 64, "src")
+        dst, ds = _plane(dst, np.float32, "dst", True)
+        k = _wt(kernel, 64, "kernel")
+        h, w = dst.shape
+        self._check(self._lib.srcnn_conv11(self._h, arr, ss, _fp(dst), ds, w, h, _fp(k), float(bias)))
+
+    def conv55(self, src, dst, kernel, bias):
+        arr, ss, _ = _ptr_array(src, 32, "src")
+        dst, ds = _plane(dst, np.uint8, "dst", True)
+        k = _wt(kernel, 800, "kernel")
+        h, w = dst.shape
+        self._check(self._lib.srcnn_conv55(self._h, arr, ss, dst.ctypes.data_as(_u8p), ds, w, h,
+                                           _fp(k), float(bias)))
+
+    def conv99x11(self, src, dst, k99, b99, k11, b11):
+        src, ss = _plane(src, np.uint8, "src")
+        arr, ds, _ = _ptr_array(dst, 32, "dst", True)
+        k99, b99 = _wt(k99, 5184, "kernel99"), _wt(b99, 64, "bias99")
+        k11, b11 = _wt(k11, 2048, "kernel11"), _wt(b11, 32, "bias11")
+        h, w = src.shape                       # dims come from src: src/srcnn.cpp:262-263
+        self._check(self._lib.srcnn_conv99x11(self._h, src.ctypes.data_as(_u8p), ss, arr, ds, w, h,
+                                              _fp(k99), _fp(b99), _fp(k11), _fp(b11)))
+
+    def forward_y(self, src, dst=None, preclamp=None):
+        """Fused Convolution99x11 + Convolution55 (needs set_weights)."""
+        src, ss = _plane(src, np.uint8, "src")
+        h, w = src.shape
+        if dst is None:
+            dst = np.empty((h, w), np.uint8)
+        dst, ds = _plane(dst, np.uint8, "dst", True)
+        pp, ps = None, 0
+        if preclamp is not None:
+            preclamp, ps = _plane(preclamp, np.float32, "preclamp", True)
+            pp = _fp(preclamp)
+        self._check(self._lib.srcnn_forward_y(self._h, src.ctypes.data_as(_u8p), ss,
+                                              dst.ctypes.data_as(_u8p), ds, w, h, pp, ps))
+        return dst
+
+    # -- device-resident entry points (integer device addresses) -------------
+    def forward_y_dev(self, d_src, src_stride, src_frame_pitch, d_dst, dst_stride, dst_frame_pitch,
+                      width, height, n_frames=1, d_preclamp=0):
+        self._check(self._lib.srcnn_forward_y_dev(self._h, d_src, src_stride, src_frame_pitch, d_dst,
+                                                  dst_stride, dst_frame_pitch, width, height, n_frames,
+                                                  d_preclamp or None))
+
+    def forward_y_rows_dev(self, d_src, src_stride, src_row0, d_dst, dst_stride, dst_row0,
+                           width, height, row_begin, row_end):
+        self._check(self._lib.srcnn_forward_y_rows_dev(self._h, d_src, src_stride, src_row0, d_dst,
+                                                       dst_stride, dst_row0, width, height,
+                                                       row_begin, row_end))
+
+    def forward_y_unfused_dev(self, d_src, src_stride, src_frame_pitch, d_dst, dst_stride,
+                              dst_frame_pitch, width, height, n_frames, d_work):
+        self._check(self._lib.srcnn_forward_y_unfused_dev(self._h, d_src, src_stride, src_frame_pitch,
+                                                          d_dst, dst_stride, dst_frame_pitch, width,
+                                                          height, n_frames, d_work))
+
+    def conv99x11_dev(self, d_src, src_stride, d_planes, plane_stride, plane_pitch, width, height):
+        self._check(self._lib.srcnn_conv99x11_dev(self._h, d_src, src_stride, d_planes, plane_stride,
+                                                  plane_pitch, width, height))
+
+    def conv55_dev(self, d_planes, plane_stride, plane_pitch, d_dst, dst_stride, width, height,
+                   d_preclamp=0):
+        self._check(self._lib.srcnn_conv55_dev(self._h, d_planes, plane_stride, plane_pitch, d_dst,
+                                               dst_stride, width, height, d_preclamp or None))
+
+
+_default: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default
+    if _default is None:
+        _default = Context(0)
+    return _default
+
+
+# The reference's free functions (src/srcnn.cpp:60-73), same names and argument order.
+def Convolution99(src, dst, kernel, bias):
+    default_context().conv99(src, dst, kernel, bias)
+
+
+def Convolution11(src: Sequence[np.ndarray], dst, kernel, bias):
+    default_context().conv11(src, dst, kernel, bias)
+
+
+def Convolution55(src: Sequence[np.ndarray], dst, kernel, bias):
+    default_context().conv55(src, dst, kernel, bias)
+
+
+def Convolution99x11(src, dst: Sequence[np.ndarray], kernel99, bias99, kernel11, bias11):
+    default_context().conv99x11(src, dst, kernel99, bias99, kernel11, bias11)

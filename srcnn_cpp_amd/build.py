@@ -1,0 +1,63 @@
+"""Build the HIP extension in-tree: srcnn_cpp_amd/libsrcnn_amd.so (gfx950 only).
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting .so is git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libsrcnn_amd.so"
+OBJ = PKG.parent / "build"
+
+ARCH = "gfx950"
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# (source, extra flags).  srcnn_exact.hip reproduces the reference's
+# multiply-then-add arithmetic: contraction to FMA must stay off there.
+UNITS = [
+    ("srcnn_mfma.hip", []),
+    ("srcnn_exact.hip", ["-ffp-contract=off"]),
+    ("srcnn_api.cpp", ["-x", "hip"]),
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _stale(target: Path, deps) -> bool:
+    return (not target.exists()) or any(d.stat().st_mtime > target.stat().st_mtime for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    headers = [CSRC / "srcnn_kernels.h", PKG.parent / "include" / "srcnn_amd.h", Path(__file__)]
+    objs = []
+    for src, extra in UNITS:
+        s = CSRC / src
+        o = OBJ / (Path(src).stem + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc()] + COMMON + extra + ["-c", str(s), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB)] + [str(o) for o in objs]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,606 @@
+// srcnn_api.cpp -- the C-ABI layer (include/srcnn_amd.h) over the HIP kernels.
+//
+// Host-side mirror of the reference's call surface: srcnn_conv99 / conv11 /
+// conv55 / conv99x11 take the same planes and weight tables as the reference's
+// Convolution99 / Convolution11 / Convolution55 / Convolution99x11
+// (src/srcnn.cpp:60-73); srcnn_forward_y is what the pipeline driver does with
+// them at src/srcnn.cpp:602-627.  Host-buffer entry points stage through
+// context-owned device buffers; *_dev entry points take device pointers.
+#include "../../include/srcnn_amd.h"
+#include "srcnn_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace srcnn;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct srcnn_ctx {
+    int device = 0;
+    int n_cu = 256;
+    int mode = SRCNN_MODE_MFMA;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = "no error";
+    // model
+    bool has_weights = false;
+    float b3 = 0.f;
+    DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
+    DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
+    // staging for the host-buffer entry points
+    DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern;
+};
+
+namespace {
+
+int fail(srcnn_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? SRCNN_ERR_NOMEM : SRCNN_ERR_HIP,     \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                         \
+    } while (0)
+
+int bind(srcnn_ctx *c)
+{
+    if (!c) return SRCNN_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return SRCNN_OK;
+}
+
+int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return SRCNN_OK;
+    if (b.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.cap = bytes;
+    return SRCNN_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+// Pack the reference-layout weights into per-lane MFMA A-operand fragments.
+// Fragment q, lane l: i = l & 31 is the accumulator row the lane's weight
+// feeds, kk = l >> 5 the k-slot (see srcnn_mfma.hip header).
+void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *w2 /*[32][64]*/,
+                    const float *b2, const float *w3 /*[32][25]*/, float *out /*[NFRAG][64]*/)
+{
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 31, kk = l >> 5;
+        const int ch = row_chan(i);
+        for (int t = 0; t < 2; ++t)
+            for (int s = 0; s < 41; ++s) {
+                const int tap = 2 * s + kk, c = 32 * t + ch;
+                out[(t * 41 + s) * 64 + l] = tap < 81 ? w1[c * 81 + tap] : b1[c];
+            }
+        for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 16; ++r)
+                out[(NFRAG_L1 + t * 16 + r) * 64 + l] = w2[ch * 64 + 32 * t + 2 * r + kk];
+        for (int r = 0; r < 16; ++r)
+            out[(NFRAG_L1 + NFRAG_L2 + r) * 64 + l] = i < 25 ? w3[(2 * r + kk) * 25 + i] : 0.f;
+        for (int r = 0; r < 16; ++r)
+            out[(NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + r) * 64 + l] = b2[2 * r + kk];
+    }
+}
+
+int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11,
+                   const float *k55, float b55)
+{
+    static const float zeros64[64] = {0};
+    static std::vector<float> zero_w(64 * 81, 0.f);
+    const float *w1 = k99 ? k99 : zero_w.data();
+    const float *b1 = b99 ? b99 : zeros64;
+    const float *w2 = k11 ? k11 : zero_w.data();
+    const float *b2 = b11 ? b11 : zeros64;
+    const float *w3 = k55 ? k55 : zero_w.data();
+    std::vector<float> frag((size_t)NFRAG * 64);
+    pack_fragments(w1, b1, w2, b2, w3, frag.data());
+    std::vector<float> raw(8129);
+    std::memcpy(raw.data(), b1, 64 * 4);
+    std::memcpy(raw.data() + 64, w1, 5184 * 4);
+    std::memcpy(raw.data() + 5248, b2, 32 * 4);
+    std::memcpy(raw.data() + 5280, w2, 2048 * 4);
+    raw[7328] = b55;
+    std::memcpy(raw.data() + 7329, w3, 800 * 4);
+    int rc;
+    if ((rc = reserve(c, c->wfrag, frag.size() * 4))) return rc;
+    if ((rc = reserve(c, c->wraw, raw.size() * 4))) return rc;
+    // synchronous copies: the host vectors die at return
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->wfrag.p, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->wraw.p, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
+    c->b3 = b55;
+    return SRCNN_OK;
+}
+
+struct Plan {
+    int seg_rows, n_strips, n_segs;
+};
+
+// Choose the row-segment height: taller segments waste fewer halo rows
+// (2*halo recomputed feature rows per segment), more segments fill the
+// 2-workgroups-per-CU slots more evenly.  Everything is regular, so scan.
+Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo)
+{
+    const int ow = FW - 2 * halo;
+    Plan best{rows, (width + ow - 1) / ow, 1};
+    const long slots = 2L * c->n_cu;
+    double best_eff = -1.0;
+    const int max_segs = std::min(rows, 4096);
+    for (int ns = 1; ns <= max_segs; ++ns) {
+        const int seg = (rows + ns - 1) / ns;
+        const int real_ns = (rows + seg - 1) / seg;
+        if (real_ns != ns) continue;
+        const long wgs = (long)best.n_strips * ns * n_frames;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double fill = (double)wgs / (double)(rounds * slots);
+        const double useful = (double)rows / ((double)ns * (seg + 2 * halo));
+        const double eff = fill * useful;
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best.seg_rows = seg;
+            best.n_segs = ns;
+        }
+    }
+    return best;
+}
+
+bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0 || h <= 0 || stride < (size_t)w; }
+
+// Common launch of the three strip modes on device memory.
+int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
+{
+    const int halo = (mode == MODE_L12) ? 0 : 2;
+    const Plan pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo);
+    p.seg_rows = pl.seg_rows;
+    p.n_strips = pl.n_strips;
+    p.n_segs = pl.n_segs;
+    p.wfrag = static_cast<const float *>(c->wfrag.p);
+    p.b3 = c->b3;
+    HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream));
+    return SRCNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srcnn_abi_version(void) { return 1; }
+
+int srcnn_create(srcnn_ctx **out, int device)
+{
+    if (!out) return SRCNN_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SRCNN_ERR_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SRCNN_ERR_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SRCNN_ERR_NODEVICE;   // gfx950 code objects only
+    srcnn_ctx *c = new (std::nothrow) srcnn_ctx();
+    if (!c) return SRCNN_ERR_NOMEM;
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SRCNN_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SRCNN_OK;
+}
+
+void srcnn_destroy(srcnn_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern})
+        release(*b);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *srcnn_last_error(const srcnn_ctx *c) { return c ? c->err : "null context"; }
+
+int srcnn_set_mode(srcnn_ctx *c, int mode)
+{
+    if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT)) return SRCNN_ERR_INVALID;
+    c->mode = mode;
+    return SRCNN_OK;
+}
+
+int srcnn_get_mode(const srcnn_ctx *c) { return c ? c->mode : SRCNN_ERR_INVALID; }
+
+int srcnn_set_stream(srcnn_ctx *c, void *hip_stream)
+{
+    if (!c) return SRCNN_ERR_INVALID;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return SRCNN_OK;
+}
+
+int srcnn_synchronize(srcnn_ctx *c)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11,
+                      const float *k55, float b55)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!k99 || !b99 || !k11 || !b11 || !k55) return fail(c, SRCNN_ERR_INVALID, "null weight table");
+    if ((rc = upload_weights(c, k99, b99, k11, b11, k55, b55))) return rc;
+    c->has_weights = true;
+    return SRCNN_OK;
+}
+
+int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[6])
+{
+    if (!c || !out || width <= 0 || height <= 0 || n_frames <= 0) return SRCNN_ERR_INVALID;
+    const Plan pl = make_plan(c, width, height, n_frames, 2);
+    out[0] = pl.n_strips * pl.n_segs * n_frames;
+    out[1] = pl.seg_rows;
+    out[2] = pl.n_strips;
+    out[3] = pl.n_segs;
+    out[4] = (int)strip_lds_bytes(MODE_FUSED);
+    out[5] = NTHREADS;
+    return SRCNN_OK;
+}
+
+/* ------------------------- device-resident entry points -------------------- */
+
+int srcnn_conv99x11_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, float *d_planes,
+                        size_t plane_stride, size_t plane_pitch, int width, int height)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_planes, plane_stride, width, height) ||
+        plane_pitch < plane_stride * (size_t)height)
+        return fail(c, SRCNN_ERR_INVALID, "conv99x11_dev: bad plane geometry");
+    if (c->mode == SRCNN_MODE_EXACT) {
+        HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, 0, d_planes, (long)plane_stride,
+                                          (long)plane_pitch, 0, width, height, 1,
+                                          static_cast<const float *>(c->wraw.p), c->stream));
+        return SRCNN_OK;
+    }
+    StripParams p{};
+    p.src = d_src;
+    p.src_stride = (long)src_stride;
+    p.planes_out = d_planes;
+    p.pl_stride = (long)plane_stride;
+    p.pl_pitch = (long)plane_pitch;
+    p.width = width;
+    p.height = height;
+    p.row_begin = 0;
+    p.row_end = height;
+    return run_strip(c, MODE_L12, p, 1);
+}
+
+int srcnn_conv55_dev(srcnn_ctx *c, const float *d_planes, size_t plane_stride, size_t plane_pitch,
+                     uint8_t *d_dst, size_t dst_stride, int width, int height, float *d_preclamp)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(d_planes, plane_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
+        plane_pitch < plane_stride * (size_t)height)
+        return fail(c, SRCNN_ERR_INVALID, "conv55_dev: bad plane geometry");
+    if (c->mode == SRCNN_MODE_EXACT) {
+        HIP_TRY(c, launch_conv55_exact(d_planes, (long)plane_stride, (long)plane_pitch, 0, d_dst, d_preclamp,
+                                       (long)dst_stride, 0, width, height, 1,
+                                       static_cast<const float *>(c->wraw.p) + 7329, c->b3, c->stream));
+        return SRCNN_OK;
+    }
+    StripParams p{};
+    p.planes_in = d_planes;
+    p.pl_stride = (long)plane_stride;
+    p.pl_pitch = (long)plane_pitch;
+    p.dst = d_dst;
+    p.pre = d_preclamp;
+    p.dst_stride = (long)dst_stride;
+    p.width = width;
+    p.height = height;
+    p.row_begin = 0;
+    p.row_end = height;
+    return run_strip(c, MODE_L3, p, 1);
+}
+
+int srcnn_forward_y_unfused_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, size_t src_frame_pitch,
+                                uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch, int width,
+                                int height, int n_frames, float *d_work)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || !d_work ||
+        n_frames <= 0)
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_unfused_dev: bad arguments");
+    const long pitch = (long)width * height;
+    if (c->mode == SRCNN_MODE_EXACT) {
+        HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, (long)src_frame_pitch, d_work, width, pitch,
+                                          32 * pitch, width, height, n_frames,
+                                          static_cast<const float *>(c->wraw.p), c->stream));
+        HIP_TRY(c, launch_conv55_exact(d_work, width, pitch, 32 * pitch, d_dst, nullptr, (long)dst_stride,
+                                       (long)dst_frame_pitch, width, height, n_frames,
+                                       static_cast<const float *>(c->wraw.p) + 7329, c->b3, c->stream));
+        return SRCNN_OK;
+    }
+    StripParams p{};
+    p.src = d_src;
+    p.src_stride = (long)src_stride;
+    p.src_frame_pitch = (long)src_frame_pitch;
+    p.planes_out = d_work;
+    p.pl_stride = width;
+    p.pl_pitch = pitch;
+    p.pl_frame_pitch = 32 * pitch;
+    p.width = width;
+    p.height = height;
+    p.row_begin = 0;
+    p.row_end = height;
+    if ((rc = run_strip(c, MODE_L12, p, n_frames))) return rc;
+    StripParams q{};
+    q.planes_in = d_work;
+    q.pl_stride = width;
+    q.pl_pitch = pitch;
+    q.pl_frame_pitch = 32 * pitch;
+    q.dst = d_dst;
+    q.dst_stride = (long)dst_stride;
+    q.dst_frame_pitch = (long)dst_frame_pitch;
+    q.width = width;
+    q.height = height;
+    q.row_begin = 0;
+    q.row_end = height;
+    return run_strip(c, MODE_L3, q, n_frames);
+}
+
+int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, size_t src_frame_pitch,
+                        uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch, int width, int height,
+                        int n_frames, float *d_preclamp)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
+        n_frames <= 0)
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: bad arguments");
+    if (c->mode == SRCNN_MODE_EXACT) {
+        const long pitch = (long)width * height;
+        if ((rc = reserve(c, c->planes, (size_t)n_frames * 32 * pitch * 4))) return rc;
+        float *work = static_cast<float *>(c->planes.p);
+        HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, (long)src_frame_pitch, work, width, pitch,
+                                          32 * pitch, width, height, n_frames,
+                                          static_cast<const float *>(c->wraw.p), c->stream));
+        HIP_TRY(c, launch_conv55_exact(work, width, pitch, 32 * pitch, d_dst, d_preclamp, (long)dst_stride,
+                                       (long)dst_frame_pitch, width, height, n_frames,
+                                       static_cast<const float *>(c->wraw.p) + 7329, c->b3, c->stream));
+        return SRCNN_OK;
+    }
+    StripParams p{};
+    p.src = d_src;
+    p.src_stride = (long)src_stride;
+    p.src_frame_pitch = (long)src_frame_pitch;
+    p.dst = d_dst;
+    p.pre = d_preclamp;
+    p.dst_stride = (long)dst_stride;
+    p.dst_frame_pitch = (long)dst_frame_pitch;
+    p.width = width;
+    p.height = height;
+    p.row_begin = 0;
+    p.row_end = height;
+    return run_strip(c, MODE_FUSED, p, n_frames);
+}
+
+int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, int src_row0,
+                             uint8_t *d_dst, size_t dst_stride, int dst_row0, int width, int height,
+                             int row_begin, int row_end)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
+        row_begin < 0 || row_end > height || row_begin >= row_end ||
+        src_row0 > std::max(0, row_begin - 6) || dst_row0 > row_begin || src_row0 < 0 || dst_row0 < 0)
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_rows_dev: bad arguments");
+    if (c->mode == SRCNN_MODE_EXACT) return fail(c, SRCNN_ERR_STATE, "row stripes are MFMA-mode only");
+    StripParams p{};
+    p.src = d_src;
+    p.src_stride = (long)src_stride;
+    p.src_row0 = src_row0;
+    p.dst = d_dst;
+    p.dst_stride = (long)dst_stride;
+    p.dst_row0 = dst_row0;
+    p.width = width;
+    p.height = height;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    return run_strip(c, MODE_FUSED, p, 1);
+}
+
+/* ------------------------- host-buffer entry points ------------------------- */
+
+int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t *dst, size_t dst_stride,
+                    int width, int height, float *preclamp, size_t preclamp_stride)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) ||
+        (preclamp && preclamp_stride < (size_t)width))
+        return fail(c, SRCNN_ERR_INVALID, "forward_y: bad plane geometry");
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->in_u8, n))) return rc;
+    if ((rc = reserve(c, c->out_u8, n))) return rc;
+    if (preclamp && (rc = reserve(c, c->pre_f32, n * 4))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src, src_stride, width, height, hipMemcpyHostToDevice,
+                                c->stream));
+    rc = srcnn_forward_y_dev(c, static_cast<uint8_t *>(c->in_u8.p), width, n,
+                             static_cast<uint8_t *>(c->out_u8.p), width, n, width, height, 1,
+                             preclamp ? static_cast<float *>(c->pre_f32.p) : nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->out_u8.p, width, width, height, hipMemcpyDeviceToHost,
+                                c->stream));
+    if (preclamp)
+        HIP_TRY(c, hipMemcpy2DAsync(preclamp, preclamp_stride * 4, c->pre_f32.p, (size_t)width * 4,
+                                    (size_t)width * 4, height, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *const *dst, size_t dst_stride,
+                    int width, int height, const float *kernel99, const float *bias99, const float *kernel11,
+                    const float *bias11)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (bad_plane(src, src_stride, width, height) || !dst || dst_stride < (size_t)width || !kernel99 ||
+        !bias99 || !kernel11 || !bias11)
+        return fail(c, SRCNN_ERR_INVALID, "conv99x11: bad arguments");
+    for (int k = 0; k < 32; ++k)
+        if (!dst[k]) return fail(c, SRCNN_ERR_INVALID, "conv99x11: null output plane %d", k);
+    // layers 1-2 of the model are replaced; layer 3 of any loaded model is kept
+    std::vector<float> w3(800, 0.f);
+    float b3 = c->b3;
+    if (c->has_weights) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(w3.data(), static_cast<float *>(c->wraw.p) + 7329, 800 * 4, hipMemcpyDeviceToHost));
+    }
+    if ((rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), b3))) return rc;
+    c->has_weights = true;
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->in_u8, n))) return rc;
+    if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src, src_stride, width, height, hipMemcpyHostToDevice,
+                                c->stream));
+    rc = srcnn_conv99x11_dev(c, static_cast<uint8_t *>(c->in_u8.p), width, static_cast<float *>(c->planes.p),
+                             width, n, width, height);
+    if (rc) return rc;
+    for (int k = 0; k < 32; ++k)
+        HIP_TRY(c, hipMemcpy2DAsync(dst[k], dst_stride * 4, static_cast<float *>(c->planes.p) + n * k,
+                                    (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost,
+                                    c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8_t *dst, size_t dst_stride,
+                 int width, int height, const float *kernel, float bias)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!src || src_stride < (size_t)width || bad_plane(dst, dst_stride, width, height) || !kernel)
+        return fail(c, SRCNN_ERR_INVALID, "conv55: bad arguments");
+    for (int k = 0; k < 32; ++k)
+        if (!src[k]) return fail(c, SRCNN_ERR_INVALID, "conv55: null input plane %d", k);
+    // layer 3 of the model is replaced; layers 1-2 of any loaded model are kept
+    std::vector<float> raw(8129, 0.f);
+    if (c->has_weights) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(raw.data(), c->wraw.p, 8129 * 4, hipMemcpyDeviceToHost));
+    }
+    if ((rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias)))
+        return rc;
+    c->has_weights = true;
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
+    if ((rc = reserve(c, c->out_u8, n))) return rc;
+    for (int k = 0; k < 32; ++k)
+        HIP_TRY(c, hipMemcpy2DAsync(static_cast<float *>(c->planes.p) + n * k, (size_t)width * 4, src[k],
+                                    src_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice,
+                                    c->stream));
+    rc = srcnn_conv55_dev(c, static_cast<float *>(c->planes.p), width, n, static_cast<uint8_t *>(c->out_u8.p),
+                          width, width, height, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->out_u8.p, width, width, height, hipMemcpyDeviceToHost,
+                                c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_conv99(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *dst, size_t dst_stride, int width,
+                 int height, const float *kernel, float bias)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) || !kernel)
+        return fail(c, SRCNN_ERR_INVALID, "conv99: bad arguments");
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->in_u8, n))) return rc;
+    if ((rc = reserve(c, c->plane1, n * 4))) return rc;
+    if ((rc = reserve(c, c->kern, 1024 * 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->kern.p, kernel, 81 * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src, src_stride, width, height, hipMemcpyHostToDevice,
+                                c->stream));
+    HIP_TRY(c, launch_conv99_exact(static_cast<uint8_t *>(c->in_u8.p), width, static_cast<float *>(c->plane1.p),
+                                   width, width, height, static_cast<float *>(c->kern.p), bias, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride * 4, c->plane1.p, (size_t)width * 4, (size_t)width * 4, height,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_conv11(srcnn_ctx *c, const float *const *src, size_t src_stride, float *dst, size_t dst_stride,
+                 int width, int height, const float *kernel, float bias)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!src || src_stride < (size_t)width || bad_plane(dst, dst_stride, width, height) || !kernel)
+        return fail(c, SRCNN_ERR_INVALID, "conv11: bad arguments");
+    for (int k = 0; k < 64; ++k)
+        if (!src[k]) return fail(c, SRCNN_ERR_INVALID, "conv11: null input plane %d", k);
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->planes, n * 64 * 4))) return rc;
+    if ((rc = reserve(c, c->plane1, n * 4))) return rc;
+    if ((rc = reserve(c, c->kern, 1024 * 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->kern.p, kernel, 64 * 4, hipMemcpyHostToDevice, c->stream));
+    for (int k = 0; k < 64; ++k)
+        HIP_TRY(c, hipMemcpy2DAsync(static_cast<float *>(c->planes.p) + n * k, (size_t)width * 4, src[k],
+                                    src_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice,
+                                    c->stream));
+    HIP_TRY(c, launch_conv11_exact(static_cast<float *>(c->planes.p), width, (long)n,
+                                   static_cast<float *>(c->plane1.p), width, width, height,
+                                   static_cast<float *>(c->kern.p), bias, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride * 4, c->plane1.p, (size_t)width * 4, (size_t)width * 4, height,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+}  // extern "C"

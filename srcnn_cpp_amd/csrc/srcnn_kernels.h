@@ -1,0 +1,71 @@
+// Internal interface between the C-ABI layer (srcnn_api.cpp) and the HIP
+// kernels.  Not installed; the public boundary is include/srcnn_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace srcnn {
+
+// ---- geometry of the strip kernels (srcnn_mfma.hip) ------------------------
+constexpr int FW = 128;            // feature columns per strip (4 waves x 32 lanes-columns)
+constexpr int YP = FW + 8;         // Y ring pitch: strip + 4-pixel layer-1 border each side
+constexpr int YR = 16;             // Y ring rows (each stored twice, see kernel)
+constexpr int NWAVES = FW / 32;    // one 32-pixel unit per wave per feature row
+constexpr int NTHREADS = NWAVES * 64;
+constexpr int ACC_ROWS = 8;        // output-row accumulator ring
+
+enum StripMode { MODE_FUSED = 0, MODE_L12 = 1, MODE_L3 = 2 };
+
+// Packed MFMA A-operand fragments, [NFRAG][64 lanes] floats (see pack_fragments()).
+constexpr int NFRAG_L1 = 82;       // 2 channel tiles x 41 k-steps (81 taps + bias tap)
+constexpr int NFRAG_L2 = 32;       // 2 x 16 k-steps over the 64 layer-1 channels
+constexpr int NFRAG_L3 = 16;       // 16 k-steps over the 32 layer-2 channels, rows = 25 taps (+7 zero)
+constexpr int NFRAG_B2 = 16;       // layer-2 bias laid out like the accumulator
+constexpr int NFRAG = NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + NFRAG_B2;
+
+// MFMA 32x32 accumulator row held by register r on lane-half h, and the
+// channel we ASSIGN to accumulator row i so that register r / half h holds
+// channel 2r+h (then the next layer's k-steps walk channels in ascending
+// order, the reference's summation order).
+__host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__host__ __device__ constexpr int row_chan(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+
+struct StripParams {
+    // layer-1 input (MODE_FUSED, MODE_L12)
+    const uint8_t *src;
+    long src_stride, src_frame_pitch;
+    int src_row0;
+    // layer-3 input (MODE_L3) / layer-2 output (MODE_L12): 32 planes in one allocation
+    const float *planes_in;
+    float *planes_out;
+    long pl_stride, pl_pitch, pl_frame_pitch;
+    // output (MODE_FUSED, MODE_L3)
+    uint8_t *dst;
+    float *pre;                     // optional pre-clamp f32, same strides as dst
+    long dst_stride, dst_frame_pitch;
+    int dst_row0;
+    const float *wfrag;
+    float b3;
+    int width, height;              // full image (border-replication domain)
+    int row_begin, row_end;         // output rows produced by this launch
+    int seg_rows, n_strips, n_segs; // workgroup decomposition
+};
+
+size_t strip_lds_bytes(int mode);
+hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream);
+
+// ---- exact (vector-ALU, reference arithmetic) kernels (srcnn_exact.hip) ----
+hipError_t launch_conv99_exact(const uint8_t *src, long sstride, float *dst, long dstride,
+                               int w, int h, const float *d_kernel81, float bias, hipStream_t st);
+hipError_t launch_conv11_exact(const float *planes, long stride, long pitch, float *dst, long dstride,
+                               int w, int h, const float *d_kernel64, float bias, hipStream_t st);
+hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_frame_pitch,
+                                  float *planes, long stride, long pitch, long frame_pitch,
+                                  int w, int h, int n_frames, const float *d_weights, hipStream_t st);
+hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, long frame_pitch,
+                               uint8_t *dst, float *pre, long dstride, long dst_frame_pitch,
+                               int w, int h, int n_frames, const float *d_kernel800, float bias,
+                               hipStream_t st);
+
+}  // namespace srcnn

@@ -1,0 +1,275 @@
+// srcnn_mfma.hip -- the MFMA strip kernels of the SRCNN Y-channel conv path
+// for gfx950 (MI355X).  Replaces the arithmetic of the reference's
+// Convolution99x11 (src/srcnn.cpp:254-325) and Convolution55 (:189-243).
+//
+// One kernel template, three modes:
+//   MODE_FUSED  u8 luma -> u8 luma; layers 1, 2, 3 chained in registers/LDS,
+//               the 64- and 32-channel maps never reach HBM;
+//   MODE_L12    u8 luma -> 32 planar f32 maps           (Convolution99x11);
+//   MODE_L3     32 planar f32 maps -> u8 luma           (Convolution55).
+//
+// Work decomposition.  A workgroup of 4 waves owns a COLUMN STRIP of FW = 128
+// feature columns and walks down a segment of rows.  Per feature row every
+// wave owns one UNIT = 32 consecutive pixels and runs, entirely in registers,
+//
+//   L1  D1[64ch][32px] = W1aug[64][82] x im2col(Y)[82][32px]     82 MFMA
+//       (81 taps + a constant-1 tap that carries the bias), ReLU
+//   L2  D2[32ch][32px] = W2[32][64]    x D1                      32 MFMA
+//       + bias, ReLU
+//   L3  T [25tap][32px] = W3t[25(32)][32ch] x D2                 16 MFMA
+//
+// with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; each instruction is
+// bit-for-bit a 2-term fmaf chain).  The weights are the A operand (channel /
+// tap on the accumulator ROW), the pixels are the B operand (pixel on the
+// LANE), so each layer's accumulator registers are directly the next layer's B
+// operands: register r of lane-half h holds accumulator row (r&3)+8(r>>2)+4h,
+// and the host packs the weight rows (row_chan()) so that this is channel
+// 2r+h -- the k-steps then visit the channels in ascending order, which is the
+// reference's summation order (src/srcnn.cpp:312-315).
+//
+// Layer 3 has a single output channel, so instead of a [P x 800] x [800 x 1]
+// product the MFMA computes, per FEATURE pixel, the 25 tap-partials
+// T[tap] = sum_c W3[c][tap] * F[c]; the output pixel is then the shifted sum
+// out(y,x) = b3 + sum_{m,n} T[5m+n](y+m-2, x+n-2) with the reference's
+// replicate border applied to the feature coordinates (src/srcnn.cpp:196-210).
+// Each finished T row is scattered through a double-buffered LDS tile into a
+// ring of output-row accumulators (5 horizontal 5-tap sums per pixel), so only
+// 2 x 25 x FW floats of T ever exist per workgroup.
+//
+// HBM traffic of MODE_FUSED is ~1.1 B read + 1 B written per pixel; the kernel
+// is bound by the f32 MFMA pipe (130 MFMA x 64 cycles per 32 pixels per SIMD).
+//
+// LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + T tiles 2x25x128 f32
+// (25 KiB) + accumulator ring 8x128 f32 (4 KiB) = 46 KiB -> two workgroups per
+// CU, i.e. two waves per SIMD, so one wave's layer seams / LDS phase are
+// covered by the other's MFMA stream.
+#include "srcnn_kernels.h"
+
+namespace srcnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *ylds = reinterpret_cast<float *>(smem);   // [2*YR][YP]   (MODE_FUSED, MODE_L12)
+    float *tbuf = ylds + 2 * YR * YP;                // [2][25][FW]  (MODE_FUSED, MODE_L3)
+    float *accr = tbuf + 2 * 25 * FW;                // [ACC_ROWS][FW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;      // pixel within the unit  (MFMA column)
+    const int half = lane >> 5;   // which of the 2 k-slots this lane feeds
+
+    constexpr int HALO = (MODE == MODE_L12) ? 0 : 2;   // layer-3 radius
+    constexpr int OWM = FW - 2 * HALO;                 // output columns per strip
+
+    const int W = p.width, H = p.height;
+    int bid = blockIdx.x;
+    const int strip = bid % p.n_strips;
+    bid /= p.n_strips;
+    const int seg = bid % p.n_segs;
+    const int frame = bid / p.n_segs;
+
+    const int xs = strip * OWM;        // first output column of the strip
+    const int gx0 = xs - HALO;         // image column of feature column xi = 0
+    const int ys = p.row_begin + seg * p.seg_rows;
+    const int ye = min(ys + p.seg_rows, p.row_end);
+    const int f_lo = max(ys - HALO, 0);
+    const int f_hi = min(ye + HALO, H);   // feature rows [f_lo, f_hi) are computed
+
+    // ---- weight fragments -> registers (A operands, one VGPR per k-step) ----
+    const float *wf = p.wfrag + lane;
+    float w1f[2][41], w2f[32], w3f[16], b2f[16];
+    if constexpr (MODE != MODE_L3) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 41; ++s) w1f[t][s] = wf[(t * 41 + s) * 64];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w2f[q] = wf[(NFRAG_L1 + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) b2f[q] = wf[(NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + q) * 64];
+    }
+    if constexpr (MODE != MODE_L12) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w3f[q] = wf[(NFRAG_L1 + NFRAG_L2 + q) * 64];
+    }
+
+    // ---- layer-1 input: rolling window of Y rows as f32 in LDS --------------
+    // Row r lives in slot r&15 AND in slot (r&15)+16, so the 9-row window that
+    // starts at slot (f-4)&15 is always contiguous and every tap is a
+    // compile-time LDS offset.  Column c of the ring is image column
+    // clamp(gx0-4+c): the reference's replicate border (src/srcnn.cpp:266-280).
+    const uint8_t *srcf = nullptr;
+    int ycol = 0;
+    if constexpr (MODE != MODE_L3) {
+        srcf = p.src + (long)frame * p.src_frame_pitch;
+        ycol = clampi(gx0 - 4 + tid, 0, W - 1);
+    }
+    auto load_y = [&](int r) -> uint8_t {
+        const int rr = clampi(r, 0, H - 1) - p.src_row0;
+        return srcf[(long)rr * p.src_stride + ycol];
+    };
+    auto stage_y = [&](int r, uint8_t v) {
+        const int slot = r & (YR - 1);
+        const float fv = (float)v;
+        ylds[slot * YP + tid] = fv;
+        ylds[(slot + YR) * YP + tid] = fv;
+    };
+    if constexpr (MODE != MODE_L3) {
+        if (tid < YP) {
+            uint8_t v[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[q] = load_y(f_lo - 4 + q);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) stage_y(f_lo - 4 + q, v[q]);
+        }
+        __syncthreads();
+    }
+
+    const int xi = 32 * wave + j;      // this lane's feature column in the strip
+    const int gx = gx0 + xi;           // ... and in the image
+
+    // layer-3 input straight from the 32 planes (MODE_L3)
+    const float *plf = nullptr;
+    if constexpr (MODE == MODE_L3)
+        plf = p.planes_in + (long)frame * p.pl_frame_pitch + clampi(gx, 0, W - 1);
+
+    for (int f = f_lo; f < f_hi; ++f) {
+        f32x16 d2;
+        if constexpr (MODE != MODE_L3) {
+            // prefetch the Y row the NEXT feature row needs
+            // (kept as the raw byte until after the MFMA stream: converting it
+            // here would make the compiler wait for the load right away)
+            unsigned ynext = 0;
+            if (tid < YP) ynext = load_y(f + 5);
+
+            // ---------------- layer 1: 82 MFMA ------------------------------
+            const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
+            const float *ybN = yb + half;                    // taps 2s | 2s+1 in one row
+            const float *ybW = yb + (half ? YP - 8 : 0);     // tap 2s = (ki,8), tap 2s+1 = (ki+1,0)
+            f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+            for (int s = 0; s < 41; ++s) {
+                const int ki = (2 * s) / 9, kj = (2 * s) % 9;
+                float b;
+                if (s == 40)
+                    b = half ? 1.0f : yb[8 * YP + 8];        // tap 80 | bias tap
+                else if (kj == 8)
+                    b = ybW[ki * YP + kj];
+                else
+                    b = ybN[ki * YP + kj];
+                a0 = MFMA(w1f[0][s], b, a0);
+                a1 = MFMA(w1f[1][s], b, a1);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[r] = fmaxf(a0[r], 0.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[r] = fmaxf(a1[r], 0.f);
+
+            // ---------------- layer 2: 32 MFMA ------------------------------
+            d2 = (f32x16){0};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[r], a0[r], d2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[16 + r], a1[r], d2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[r] = fmaxf(d2[r] + b2f[r], 0.f);
+
+            asm volatile("" : "+v"(ynext));
+            if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
+
+            if constexpr (MODE == MODE_L12) {
+                // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
+                if (gx < W) {
+                    float *o = p.planes_out + (long)frame * p.pl_frame_pitch + (long)f * p.pl_stride + gx;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(long)(2 * r + half) * p.pl_pitch] = d2[r];
+                }
+            }
+        } else {
+            const float *q = plf + (long)f * p.pl_stride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[r] = q[(long)(2 * r + half) * p.pl_pitch];
+        }
+
+        if constexpr (MODE != MODE_L12) {
+            // ---------------- layer 3 tap partials: 16 MFMA ------------------
+            f32x16 t = {0};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
+            float *tb = tbuf + (f & 1) * 25 * FW + xi;
+#pragma unroll
+            for (int r = 0; r < 12; ++r) tb[acc_row(r, 0) * FW + 4 * half * FW] = t[r];
+            if (half == 0) tb[24 * FW] = t[12];
+        }
+
+        __syncthreads();
+
+        if constexpr (MODE != MODE_L12) {
+            // ---------------- scatter-accumulate T row f ---------------------
+            // out(y,x) += c_m(x) for every (y,m) with clamp(y+m-2) == f, m ascending,
+            // c_m(x) = sum_n T[5m+n](f, clamp(x+n-2)).
+            if (half == 0) {
+                const float *tr = tbuf + (f & 1) * 25 * FW;
+                int xn[5];
+#pragma unroll
+                for (int n = 0; n < 5; ++n)
+                    xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+                const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    float cm = tr[(5 * m) * FW + xn[0]];
+#pragma unroll
+                    for (int n = 1; n < 5; ++n) cm += tr[(5 * m + n) * FW + xn[n]];
+                    int y0 = (f == 0) ? 0 : f - m + 2;
+                    int y1 = (f == H - 1) ? H - 1 : f - m + 2;
+                    y0 = max(y0, ys);
+                    y1 = min(y1, ye - 1);
+                    for (int y = y0; y <= y1; ++y) {
+                        float *ap = accr + (y & (ACC_ROWS - 1)) * FW + xi;
+                        const float acc = (m == 0) ? cm : *ap + cm;
+                        if (m < 4) {
+                            *ap = acc;
+                        } else if (px_ok) {
+                            const float v = acc + p.b3;
+                            const long o = (long)frame * p.dst_frame_pitch +
+                                           (long)(y - p.dst_row0) * p.dst_stride + gx;
+                            if (p.pre) p.pre[o] = v;
+                            // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240
+                            p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+size_t strip_lds_bytes(int /*mode*/)
+{
+    return sizeof(float) * (2 * YR * YP + 2 * 25 * FW + ACC_ROWS * FW);
+}
+
+hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
+    const dim3 block(NTHREADS);
+    const size_t lds = strip_lds_bytes(mode);
+    switch (mode) {
+    case MODE_FUSED: hipLaunchKernelGGL(srcnn_strip_kernel<MODE_FUSED>, grid, block, lds, stream, p); break;
+    case MODE_L12:   hipLaunchKernelGGL(srcnn_strip_kernel<MODE_L12>, grid, block, lds, stream, p); break;
+    case MODE_L3:    hipLaunchKernelGGL(srcnn_strip_kernel<MODE_L3>, grid, block, lds, stream, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace srcnn

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/srcnn_amd.h declares; argument validation and the
+"no GPU -> loud failure, no CPU fallback" contract.  No compute calls."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd import build as B
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    B.build()                      # hipcc cross-compiles gfx950 without a GPU
+    return S.load_library()
+
+
+def header_symbols():
+    text = (ROOT / "include" / "srcnn_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(srcnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in srcnn_amd.h but not exported"
+    assert sorted(S.ABI_SYMBOLS) == syms
+    assert lib.srcnn_abi_version() == 1
+
+
+def test_no_torch_or_hip_types_in_header():
+    text = (ROOT / "include" / "srcnn_amd.h").read_text()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for banned in ("hipStream_t", "at::", "torch", "cv::", "std::"):
+        assert banned not in code
+
+
+def test_reference_mirror_header_compiles():
+    """include/srcnn_amd.hpp restates the reference prototypes (src/srcnn.cpp:60-73)
+    over the C ABI; it must compile as plain C++ without OpenCV or HIP."""
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "t.cpp"
+        src.write_text('#include "srcnn_amd.hpp"\n'
+                       'int main(){ srcnn::Plane<unsigned char> y(4,3); srcnn::Plane<float> f(4,3);\n'
+                       ' return (y.rows==3 && f.cols==4) ? 0 : 1; }\n')
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{ROOT / 'include'}", str(src)], check=True)
+
+
+def test_create_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tests")
+    h = ctypes.c_void_p()
+    assert lib.srcnn_create(ctypes.byref(h), 0) == -4          # SRCNN_ERR_NODEVICE
+    assert not h
+    with pytest.raises(S.SrcnnError):
+        S.Context(0)
+    with pytest.raises(S.SrcnnError):
+        S.Convolution99(np.zeros((4, 4), np.uint8), np.zeros((4, 4), np.float32), np.zeros(81, np.float32), 0.0)
+
+
+def test_null_and_bad_arguments(lib):
+    assert lib.srcnn_create(None, 0) == -1
+    assert lib.srcnn_set_mode(None, 0) == -1
+    assert lib.srcnn_get_mode(None) == -1
+    assert lib.srcnn_last_error(None) == b"null context"
+    lib.srcnn_destroy(None)                                    # harmless
+
+
+def test_python_binding_validates_planes():
+    with pytest.raises(TypeError):
+        S._plane(np.zeros((4, 4), np.float32), np.uint8, "src")
+    with pytest.raises(ValueError):
+        S._plane(np.zeros((4, 8), np.uint8)[:, ::2], np.uint8, "src")
+    a, stride = S._plane(np.zeros((4, 8), np.uint8)[:, :5], np.uint8, "src")
+    assert stride == 8
+
+
+def test_exact_kernels_have_no_fused_multiply_add(tmp_path):
+    """srcnn_exact.hip must keep the reference's multiply-then-add arithmetic."""
+    import subprocess
+    out = tmp_path / "exact.s"
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                    "--cuda-device-only", "-o", str(out), str(B.CSRC / "srcnn_exact.hip")],
+                   check=True, stderr=subprocess.DEVNULL)
+    asm = out.read_text()
+    assert "v_mul_f32" in asm and "v_add_f32" in asm and "v_add_f64" in asm
+    for banned in ("v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_mad_f32", "v_pk_fma_f32", "v_fma_f64",
+                   "v_fma_mix"):
+        assert banned not in asm, banned

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path, called THROUGH THE C ABI, against the oracle.
+
+Two kinds of comparison:
+
+* vs ``oracle.*``          -- the reference's arithmetic (strict multiply-then-add,
+                              src/srcnn.cpp:92-325).  This is the parity claim.
+                              SRCNN_MODE_EXACT and the per-filter entry points
+                              (Convolution99 / Convolution11) must be BIT-EXACT;
+                              the MFMA path must be within the float32 tolerance
+                              below.
+* vs ``oracle.gpuorder_*`` -- a CPU model of the MFMA kernels' summation order
+                              (FMA chains); must be BITWISE equal, so a layout or
+                              indexing bug can never hide inside the tolerance.
+
+Float32 tolerance of the MFMA path vs the reference arithmetic (north_star:
+"within a stated float32 tolerance"):
+    32-channel map after layer 2 : |d| <= 1e-3 * max(1, |ref|)
+    pre-clamp f32 output         : |d| <= 5e-3   (0..255 scale)
+    u8 output                    : |d| <= 1 LSB everywhere, mismatches <= 1e-3 of pixels
+"""
+import numpy as np
+import pytest
+
+import oracle
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_luma, synth_batch
+
+pytestmark = pytest.mark.gpu
+
+TOL_MAP_REL = 1e-3
+TOL_PRE_ABS = 5e-3
+TOL_U8_FRAC = 1e-3
+
+EDGE_SIZES = [(1, 1), (3, 3), (9, 5), (5, 9), (17, 4), (2, 40), (40, 2), (31, 7), (33, 9)]
+TILE_SIZES = [(123, 11), (124, 13), (125, 9), (127, 6), (128, 20), (129, 10), (248, 7), (249, 8),
+              (300, 70), (97, 61)]
+
+
+def planes32(h, w, stride=None):
+    stride = stride or w
+    buf = np.zeros((32, h, stride), np.float32)
+    return buf, [buf[k, :, :w] for k in range(32)]
+
+
+def check_u8(got, ref):
+    d = np.abs(got.astype(int) - ref.astype(int))
+    assert d.max() <= 1, f"u8 differs by {d.max()} LSB"
+    assert (d != 0).mean() <= TOL_U8_FRAC, f"{(d != 0).mean():.2e} of pixels differ"
+
+
+# ---------------------------------------------------------------- Convolution99 / 11 (bit-exact)
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + [(97, 61), (200, 33)])
+def test_conv99_bit_exact(gpu_ctx, weights_blob, w, h):
+    w1, b1, *_ = S.split_weights(weights_blob)
+    y = synth_luma(w, h, frame=2)
+    for k in (0, 8, 63):
+        dst = np.full((h, w), -7.0, np.float32)
+        gpu_ctx.conv99(y, dst, w1[k], b1[k])
+        assert np.array_equal(dst, oracle.conv99(y, w1[k], b1[k]))
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (9, 5), (70, 33), (129, 17)])
+def test_conv11_bit_exact(gpu_ctx, weights_blob, w, h):
+    w1, b1, w2, b2, *_ = S.split_weights(weights_blob)
+    rng = np.random.default_rng(w * 1000 + h)
+    src = (rng.random((64, h, w), dtype=np.float32) * 300).astype(np.float32)
+    src[rng.random((64, h, w)) < 0.4] = 0
+    for k in (0, 31):
+        dst = np.empty((h, w), np.float32)
+        gpu_ctx.conv11([src[i] for i in range(64)], dst, w2[k], b2[k])
+        assert np.array_equal(dst, oracle.conv11(src, w2[k], b2[k]))
+
+
+def test_unfused_surface_equals_fused_oracle(gpu_ctx, weights_blob):
+    """64 x Convolution99 then 32 x Convolution11 on the GPU == the reference's
+    fused Convolution99x11, bit for bit."""
+    w1, b1, w2, b2, *_ = S.split_weights(weights_blob)
+    y = synth_luma(45, 23, frame=5)
+    l1 = np.empty((64, 23, 45), np.float32)
+    for k in range(64):
+        gpu_ctx.conv99(y, l1[k], w1[k], b1[k])
+    l2 = np.empty((32, 23, 45), np.float32)
+    for k in range(32):
+        gpu_ctx.conv11([l1[i] for i in range(64)], l2[k], w2[k], b2[k])
+    assert np.array_equal(l2, oracle.conv99x11(y, w1, b1, w2, b2))
+
+
+# ---------------------------------------------------------------- Convolution99x11 (MFMA)
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + TILE_SIZES)
+def test_conv99x11_mfma(gpu_ctx, weights_blob, w, h):
+    w1, b1, w2, b2, *_ = S.split_weights(weights_blob)
+    y = synth_luma(w, h, frame=1)
+    buf, dst = planes32(h, w)
+    buf[:] = -1.0
+    gpu_ctx.conv99x11(y, dst, w1, b1, w2, b2)
+    model = oracle.gpuorder_conv99x11(y, w1, b1, w2, b2)
+    assert np.array_equal(buf, model), "MFMA layer 1-2 differs from its FMA-order model"
+    ref = oracle.conv99x11(y, w1, b1, w2, b2)
+    assert (np.abs(buf - ref) <= TOL_MAP_REL * np.maximum(1.0, np.abs(ref))).all()
+
+
+def test_conv99x11_strided_planes(gpu_ctx, weights_blob):
+    w1, b1, w2, b2, *_ = S.split_weights(weights_blob)
+    ybuf = np.zeros((30, 80), np.uint8)
+    ybuf[:, :71] = synth_luma(71, 30)
+    y = ybuf[:, :71]
+    buf, dst = planes32(30, 71, stride=96)
+    buf[:] = np.float32(-5)
+    gpu_ctx.conv99x11(y, dst, w1, b1, w2, b2)
+    assert np.array_equal(buf[:, :, :71], oracle.gpuorder_conv99x11(np.ascontiguousarray(y), w1, b1, w2, b2))
+    assert (buf[:, :, 71:] == -5).all(), "wrote outside the plane's columns"
+
+
+# ---------------------------------------------------------------- Convolution55 (MFMA)
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + TILE_SIZES)
+def test_conv55_mfma(gpu_ctx, weights_blob, w, h):
+    w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
+    feat = oracle.conv99x11(synth_luma(w, h, frame=4), w1, b1, w2, b2)
+    dst = np.full((h, w), 77, np.uint8)
+    gpu_ctx.conv55([feat[k] for k in range(32)], dst, w3, b3)
+    model, _ = oracle.gpuorder_conv55(feat, w3, b3)
+    assert np.array_equal(dst, model), "MFMA layer 3 differs from its FMA-order model"
+    ref, _ = oracle.conv55(feat, w3, b3)
+    check_u8(dst, ref)
+
+
+# ---------------------------------------------------------------- whole path, fused kernel
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + TILE_SIZES)
+def test_forward_fused(gpu_ctx, weights_blob, w, h):
+    y = synth_luma(w, h)
+    pre = np.empty((h, w), np.float32)
+    out = gpu_ctx.forward_y(y, preclamp=pre)
+    m_out, m_pre = oracle.gpuorder_forward_y(y, weights_blob)
+    assert np.array_equal(pre, m_pre), "fused kernel differs from its FMA-order model (pre-clamp)"
+    assert np.array_equal(out, m_out)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
+    check_u8(out, r_out)
+
+
+@pytest.mark.parametrize("value", [0, 1, 128, 255])
+def test_forward_constant_images(gpu_ctx, weights_blob, value):
+    y = np.full((37, 150), value, np.uint8)
+    out = gpu_ctx.forward_y(y)
+    r_out, _ = oracle.forward_y(y, weights_blob)
+    check_u8(out, r_out)
+    assert (out == out[0, 0]).all()
+
+
+def test_forward_saturating_input(gpu_ctx, weights_blob):
+    """i.i.d. bytes drive the output into the 0/255 clamp (src/srcnn.cpp:238)."""
+    y = np.random.default_rng(7).integers(0, 256, (64, 140), dtype=np.uint8)
+    out = gpu_ctx.forward_y(y)
+    m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
+    r_out, _ = oracle.forward_y(y, weights_blob)
+    assert np.array_equal(out, m_out)
+    assert ((r_out == 0) | (r_out == 255)).mean() > 0.2
+    check_u8(out, r_out)
+
+
+def test_forward_strided_host_planes(gpu_ctx, weights_blob):
+    ybuf = np.zeros((41, 160), np.uint8)
+    ybuf[:, 3:133] = synth_luma(130, 41)
+    y = ybuf[:, 3:133]
+    obuf = np.full((41, 200), 9, np.uint8)
+    gpu_ctx.forward_y(y, dst=obuf[:, :130])
+    m_out, _ = oracle.gpuorder_forward_y(np.ascontiguousarray(y), weights_blob)
+    assert np.array_equal(obuf[:, :130], m_out)
+    assert (obuf[:, 130:] == 9).all()
+
+
+def test_butterfly_fixture(gpu_ctx, weights_blob):
+    """configs[0] input (butterfly.png x1.5) through the GPU path: equals the
+    oracle within tolerance and lands on the reference's own output picture."""
+    from pathlib import Path
+    gold = Path(__file__).resolve().parent / "golden"
+    y_in = np.fromfile(gold / "butterfly_y_in_576.u8", np.uint8).reshape(576, 576)
+    y_ref = np.fromfile(gold / "butterfly_y_ref_576.u8", np.uint8).reshape(576, 576)
+    out = gpu_ctx.forward_y(y_in)
+    r_out, _ = oracle.forward_y(y_in, weights_blob)
+    check_u8(out, r_out)
+    d = out.astype(np.float64) - y_ref
+    assert 10 * np.log10(255.0 ** 2 / np.mean(d * d)) >= 50.0
+
+
+# ---------------------------------------------------------------- SRCNN_MODE_EXACT (bit-exact)
+
+@pytest.mark.parametrize("w,h", [(1, 1), (9, 5), (5, 9), (97, 61), (130, 20)])
+def test_exact_mode_bit_exact(gpu_ctx, weights_blob, w, h):
+    w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
+    y = synth_luma(w, h, frame=6)
+    gpu_ctx.set_mode(S.MODE_EXACT)
+    try:
+        pre = np.empty((h, w), np.float32)
+        out = gpu_ctx.forward_y(y, preclamp=pre)
+        buf, dst = planes32(h, w)
+        gpu_ctx.conv99x11(y, dst, w1, b1, w2, b2)
+        o55 = np.empty((h, w), np.uint8)
+        gpu_ctx.conv55([buf[k] for k in range(32)], o55, w3, b3)
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+        gpu_ctx.set_weights_blob(weights_blob)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert np.array_equal(buf, oracle.conv99x11(y, w1, b1, w2, b2))
+    assert np.array_equal(pre, r_pre)
+    assert np.array_equal(out, r_out) and np.array_equal(o55, r_out)
+
+
+# ---------------------------------------------------------------- device-resident API, batches, stripes
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_device_batch_and_unfused_agree(gpu_ctx, weights_blob):
+    """configs[2] shape in miniature: a batch of frames through the fused kernel
+    and through the materialising (layer-1/2 kernel + layer-3 kernel) path give
+    identical bytes, and each frame equals the single-frame result."""
+    torch = _torch()
+    n, h, w = 5, 45, 200
+    frames = synth_batch(w, h, n)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    d_out2 = torch.zeros_like(d_in)
+    d_work = torch.empty((n, 32, h, w), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.forward_y_dev(d_in.data_ptr(), w, h * w, d_out.data_ptr(), w, h * w, w, h, n)
+    gpu_ctx.forward_y_unfused_dev(d_in.data_ptr(), w, h * w, d_out2.data_ptr(), w, h * w, w, h, n,
+                                  d_work.data_ptr())
+    gpu_ctx.synchronize()
+    a, b = d_out.cpu().numpy(), d_out2.cpu().numpy()
+    assert np.array_equal(a, b)
+    for k in range(n):
+        m_out, _ = oracle.gpuorder_forward_y(frames[k], weights_blob)
+        assert np.array_equal(a[k], m_out)
+
+
+@pytest.mark.parametrize("n_stripes", [2, 3, 8])
+def test_row_stripes_equal_whole_image(gpu_ctx, weights_blob, n_stripes):
+    """configs[3] in miniature: row stripes with a 6-row input halo stitch to the
+    whole-image result bit for bit (image edges replicate, stripe edges do not)."""
+    torch = _torch()
+    h, w = 90, 260
+    y = synth_luma(w, h, frame=9)
+    whole = gpu_ctx.forward_y(y)
+    out = np.zeros_like(y)
+    bounds = np.linspace(0, h, n_stripes + 1).astype(int)
+    for s in range(n_stripes):
+        r0, r1 = int(bounds[s]), int(bounds[s + 1])
+        s0, s1 = max(0, r0 - 6), min(h, r1 + 6)
+        d_in = torch.from_numpy(np.ascontiguousarray(y[s0:s1])).cuda()
+        d_out = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.forward_y_rows_dev(d_in.data_ptr(), w, s0, d_out.data_ptr(), w, r0, w, h, r0, r1)
+        gpu_ctx.synchronize()
+        out[r0:r1] = d_out.cpu().numpy()
+    assert np.array_equal(out, whole)
+
+
+def test_full_size_4k_frame(gpu_ctx, weights_blob):
+    """configs[1] at full size (3840x2160).  The whole frame is checked bitwise
+    against the FMA-order model; parity with the reference arithmetic is checked
+    on the whole frame too (oracle, all host cores)."""
+    w, h = 3840, 2160
+    y = synth_luma(w, h)
+    pre = np.empty((h, w), np.float32)
+    out = gpu_ctx.forward_y(y, preclamp=pre)
+    # size-independent property: 13x13 locality -- crops reproduce the frame
+    for (r0, c0) in [(0, 0), (1000, 2000), (h - 80, w - 200), (0, w - 150), (h - 64, 0)]:
+        r1, c1 = min(h, r0 + 80), min(w, c0 + 200)
+        crop = np.ascontiguousarray(y[r0:r1, c0:c1])
+        c_out = gpu_ctx.forward_y(crop)
+        ir0, ic0 = (0 if r0 == 0 else 6), (0 if c0 == 0 else 6)
+        ir1, ic1 = (r1 - r0 if r1 == h else r1 - r0 - 6), (c1 - c0 if c1 == w else c1 - c0 - 6)
+        assert np.array_equal(c_out[ir0:ir1, ic0:ic1], out[r0 + ir0:r0 + ir1, c0 + ic0:c0 + ic1])
+    m_out, m_pre = oracle.gpuorder_forward_y(y, weights_blob)
+    assert np.array_equal(pre, m_pre)
+    assert np.array_equal(out, m_out)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
+    check_u8(out, r_out)
+
+
+def test_error_paths(gpu_ctx):
+    with pytest.raises(S.SrcnnError):
+        gpu_ctx.forward_y_dev(0, 10, 100, 0, 10, 100, 10, 10, 1)
+    ctx2 = S.Context(0)
+    with pytest.raises(S.SrcnnError) as e:
+        ctx2.forward_y(np.zeros((4, 4), np.uint8))
+    assert e.value.code == -5            # SRCNN_ERR_STATE: no weights yet
+    with pytest.raises(S.SrcnnError):
+        S.Context(99)
+    ctx2.close()
