@@ -86,7 +86,9 @@ def main():
     W, H, F = args.width, args.height, args.frames
     ctx = S.Context(local_rank)
     ctx.set_weights_blob(S.load_weights())
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream that both torch's events and the HIP kernels use
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     # each rank owns its frames (frame-sharded stream; no data-path collective)

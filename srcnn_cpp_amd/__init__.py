@@ -68,6 +68,14 @@ def load_library() -> C.CDLL:
     if not _LIB_PATH.exists():
         raise SrcnnError(-4, f"{_LIB_PATH} not built: run `python -m srcnn_cpp_amd.build` "
                              "(there is no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process must hold ONE
+    # HIP runtime or torch tensors/streams and this library would not share a device
+    # context.  Importing torch first makes the dynamic linker resolve our NEEDED
+    # libamdhip64.so.7 to the copy torch already loaded (same SONAME).
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     lib = C.CDLL(str(_LIB_PATH))
     sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
     sigs = {

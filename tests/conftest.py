@@ -2,6 +2,7 @@ import sys
 from pathlib import Path
 
 import pytest
+import torch  # noqa: F401  -- before the HIP library, so one HIP runtime serves both
 
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:

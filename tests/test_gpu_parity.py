@@ -16,7 +16,10 @@ Float32 tolerance of the MFMA path vs the reference arithmetic (north_star:
 "within a stated float32 tolerance"):
     32-channel map after layer 2 : |d| <= 1e-3 * max(1, |ref|)
     pre-clamp f32 output         : |d| <= 5e-3   (0..255 scale)
-    u8 output                    : |d| <= 1 LSB everywhere, mismatches <= 1e-3 of pixels
+    u8 output                    : |d| <= 1 LSB everywhere; a pixel may differ ONLY where the
+                                   reference's pre-truncation value lies within 5e-3 of an
+                                   integer (the store truncates, src/srcnn.cpp:238-240);
+                                   on planes >= 1e5 pixels mismatches <= 1e-3 of pixels
 """
 import numpy as np
 import pytest
@@ -42,10 +45,14 @@ def planes32(h, w, stride=None):
     return buf, [buf[k, :, :w] for k in range(32)]
 
 
-def check_u8(got, ref):
+def check_u8(got, ref, ref_pre=None):
     d = np.abs(got.astype(int) - ref.astype(int))
     assert d.max() <= 1, f"u8 differs by {d.max()} LSB"
-    assert (d != 0).mean() <= TOL_U8_FRAC, f"{(d != 0).mean():.2e} of pixels differ"
+    if ref_pre is not None and d.any():
+        near = np.abs(ref_pre - np.rint(ref_pre))[d != 0]
+        assert near.max() <= TOL_PRE_ABS, "u8 mismatch away from a truncation boundary"
+    if d.size >= 100000 or ref_pre is None:
+        assert (d != 0).sum() <= max(2, TOL_U8_FRAC * d.size), f"{(d != 0).sum()} of {d.size} pixels differ"
 
 
 # ---------------------------------------------------------------- Convolution99 / 11 (bit-exact)
@@ -123,8 +130,8 @@ def test_conv55_mfma(gpu_ctx, weights_blob, w, h):
     gpu_ctx.conv55([feat[k] for k in range(32)], dst, w3, b3)
     model, _ = oracle.gpuorder_conv55(feat, w3, b3)
     assert np.array_equal(dst, model), "MFMA layer 3 differs from its FMA-order model"
-    ref, _ = oracle.conv55(feat, w3, b3)
-    check_u8(dst, ref)
+    ref, ref_pre = oracle.conv55(feat, w3, b3)
+    check_u8(dst, ref, ref_pre)
 
 
 # ---------------------------------------------------------------- whole path, fused kernel
@@ -139,15 +146,15 @@ def test_forward_fused(gpu_ctx, weights_blob, w, h):
     assert np.array_equal(out, m_out)
     r_out, r_pre = oracle.forward_y(y, weights_blob)
     assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
-    check_u8(out, r_out)
+    check_u8(out, r_out, r_pre)
 
 
 @pytest.mark.parametrize("value", [0, 1, 128, 255])
 def test_forward_constant_images(gpu_ctx, weights_blob, value):
     y = np.full((37, 150), value, np.uint8)
     out = gpu_ctx.forward_y(y)
-    r_out, _ = oracle.forward_y(y, weights_blob)
-    check_u8(out, r_out)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    check_u8(out, r_out, r_pre)
     assert (out == out[0, 0]).all()
 
 
@@ -156,10 +163,10 @@ def test_forward_saturating_input(gpu_ctx, weights_blob):
     y = np.random.default_rng(7).integers(0, 256, (64, 140), dtype=np.uint8)
     out = gpu_ctx.forward_y(y)
     m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
-    r_out, _ = oracle.forward_y(y, weights_blob)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
     assert np.array_equal(out, m_out)
     assert ((r_out == 0) | (r_out == 255)).mean() > 0.2
-    check_u8(out, r_out)
+    check_u8(out, r_out, r_pre)
 
 
 def test_forward_strided_host_planes(gpu_ctx, weights_blob):
@@ -181,8 +188,8 @@ def test_butterfly_fixture(gpu_ctx, weights_blob):
     y_in = np.fromfile(gold / "butterfly_y_in_576.u8", np.uint8).reshape(576, 576)
     y_ref = np.fromfile(gold / "butterfly_y_ref_576.u8", np.uint8).reshape(576, 576)
     out = gpu_ctx.forward_y(y_in)
-    r_out, _ = oracle.forward_y(y_in, weights_blob)
-    check_u8(out, r_out)
+    r_out, r_pre = oracle.forward_y(y_in, weights_blob)
+    check_u8(out, r_out, r_pre)
     d = out.astype(np.float64) - y_ref
     assert 10 * np.log10(255.0 ** 2 / np.mean(d * d)) >= 50.0
 
@@ -284,7 +291,7 @@ def test_full_size_4k_frame(gpu_ctx, weights_blob):
     assert np.array_equal(out, m_out)
     r_out, r_pre = oracle.forward_y(y, weights_blob)
     assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
-    check_u8(out, r_out)
+    check_u8(out, r_out, r_pre)
 
 
 def test_error_paths(gpu_ctx):
