@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -40,7 +41,7 @@ struct srcnn_ctx {
     DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
     DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
     // staging for the host-buffer entry points
-    DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern;
+    DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
 };
 
 namespace {
@@ -137,6 +138,7 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     std::memcpy(raw.data() + 7329, w3, 800 * 4);
     int rc;
     if ((rc = reserve(c, c->wfrag, frag.size() * 4))) return rc;
+    if ((rc = reserve(c, c->sink, 1 << 20))) return rc;   // scratch words (+ diagnostics in debug builds)
     if ((rc = reserve(c, c->wraw, raw.size() * 4))) return rc;
     // synchronous copies: the host vectors die at return
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -189,8 +191,14 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.n_strips = pl.n_strips;
     p.n_segs = pl.n_segs;
     p.wfrag = static_cast<const float *>(c->wfrag.p);
+    p.sink = static_cast<float *>(c->sink.p);
     p.b3 = c->b3;
-    HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream));
+    // undocumented experiment knobs (never set in production)
+    static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
+    static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
+    p.tune = env_tune ? std::atoi(env_tune) : 0;
+    const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
+    HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     return SRCNN_OK;
 }
 
@@ -228,7 +236,7 @@ void srcnn_destroy(srcnn_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern})
+    for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink})
         release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -268,6 +276,17 @@ int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const fl
     if (!k99 || !b99 || !k11 || !b11 || !k55) return fail(c, SRCNN_ERR_INVALID, "null weight table");
     if ((rc = upload_weights(c, k99, b99, k11, b11, k55, b55))) return rc;
     c->has_weights = true;
+    return SRCNN_OK;
+}
+
+/* Undocumented diagnostics hook (not part of the ABI): copy the scratch buffer to the host. */
+int srcnn_debug_read_sink(srcnn_ctx *c, void *dst, size_t bytes)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!dst || bytes > c->sink.cap) return SRCNN_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, c->sink.p, bytes, hipMemcpyDeviceToHost));
     return SRCNN_OK;
 }
 

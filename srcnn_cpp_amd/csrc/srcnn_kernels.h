@@ -46,14 +46,16 @@ struct StripParams {
     long dst_stride, dst_frame_pitch;
     int dst_row0;
     const float *wfrag;
+    float *sink;                    // >= 128 floats of scratch for predicated-off stores
     float b3;
     int width, height;              // full image (border-replication domain)
     int row_begin, row_end;         // output rows produced by this launch
     int seg_rows, n_strips, n_segs; // workgroup decomposition
+    int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
 };
 
 size_t strip_lds_bytes(int mode);
-hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream);
+hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 
 // ---- exact (vector-ALU, reference arithmetic) kernels (srcnn_exact.hip) ----
 hipError_t launch_conv99_exact(const uint8_t *src, long sstride, float *dst, long dstride,

@@ -40,10 +40,12 @@
 // is bound by the f32 MFMA pipe (130 MFMA x 64 cycles per 32 pixels per SIMD).
 //
 // LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + T tiles 2x25x128 f32
-// (25 KiB) + accumulator ring 8x128 f32 (4 KiB) = 46 KiB -> two workgroups per
+// (25 KiB) + accumulator ring 9x128 f32 (4.5 KiB) = 46.5 KiB -> two workgroups per
 // CU, i.e. two waves per SIMD, so one wave's layer seams / LDS phase are
 // covered by the other's MFMA stream.
 #include "srcnn_kernels.h"
+
+#include <type_traits>
 
 namespace srcnn {
 
@@ -53,13 +55,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-template <int MODE>
+// ReLU as ONE v_max_f32 (fmaxf() adds a canonicalising v_max first).  For finite x,
+// max(x, 0) equals the reference's (x < 0) ? 0 : x  (src/srcnn.cpp:304,319) up to the sign of zero.
+__device__ __forceinline__ float relu(float x)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+template <int MODE, bool PRE, bool DIAG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *ylds = reinterpret_cast<float *>(smem);   // [2*YR][YP]   (MODE_FUSED, MODE_L12)
     float *tbuf = ylds + 2 * YR * YP;                // [2][25][FW]  (MODE_FUSED, MODE_L3)
-    float *accr = tbuf + 2 * 25 * FW;                // [ACC_ROWS][FW]
+    float *accr = tbuf + 2 * 25 * FW;                // [ACC_ROWS + 1][FW], last row = write sink
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,6 +145,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         __syncthreads();
     }
 
+    // DIAG build only (SRCNN_DEBUG_TUNE & 2): cycle stamps -> p.sink, never an output
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    unsigned long long dg_t0 = 0, dg_r0 = 0, dg_l1 = 0, dg_l23 = 0, dg_bar = 0, dg_top = 0;
+    if constexpr (DIAG) {
+        dg_t0 = stamp();
+        dg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
+
     const int xi = 32 * wave + j;      // this lane's feature column in the strip
     const int gx = gx0 + xi;           // ... and in the image
 
@@ -142,7 +165,100 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     if constexpr (MODE == MODE_L3)
         plf = p.planes_in + (long)frame * p.pl_frame_pitch + clampi(gx, 0, W - 1);
 
-    for (int f = f_lo; f < f_hi; ++f) {
+    // ---- layer-3 scatter-accumulate ("phase B") ------------------------------
+    // out(y,x) += c_m(x) for every (y,m) with clamp(y+m-2) == g, m ascending,
+    // c_m(x) = sum_n T[5m+n](g, clamp(x+n-2)).  Lanes l and l+32 own the same
+    // pixel and do identical work (no divergence; duplicate stores are benign).
+    int xn[5] = {0, 0, 0, 0, 0};
+    bool px_ok = false;
+    if constexpr (MODE != MODE_L12) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+        px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+    }
+    auto finalize = [&](int y, float acc, bool ok) {
+        const float v = acc + p.b3;
+        const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
+        // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own
+        // no output pixel store to a scratch word instead of branching around the store.
+        uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
+        *d8 = (uint8_t)clampi((int)v, 0, 255);
+        if constexpr (PRE) {
+            float *dp = ok ? p.pre + o : p.sink + 64 + lane;
+            *dp = v;
+        }
+    };
+    // any T row, including the image's first/last row (which feed several
+    // output rows per m through the replicate border)
+    auto pb_generic = [&](int g) {
+        const float *tr = tbuf + (g & 1) * 25 * FW;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            float cm = tr[(5 * m) * FW + xn[0]];
+#pragma unroll
+            for (int n = 1; n < 5; ++n) cm += tr[(5 * m + n) * FW + xn[n]];
+            int y0 = (g == 0) ? 0 : g - m + 2;
+            int y1 = (g == H - 1) ? H - 1 : g - m + 2;
+            y0 = max(y0, ys);
+            y1 = min(y1, ye - 1);
+            for (int y = y0; y <= y1; ++y) {
+                float *ap = accr + (y & (ACC_ROWS - 1)) * FW + xi;
+                const float acc = (m == 0) ? cm : *ap + cm;
+                if (m < 4) *ap = acc;
+                else finalize(y, acc, px_ok);
+            }
+        }
+    };
+    // interior T row (0 < g < H-1): exactly one output row per m, y = g-m+2.
+    // Branch-free (rows outside the segment go to the sink row / scratch word)
+    // and split in a load half and a use half, so it can sit INSIDE the
+    // layer-1 MFMA stream with its LDS latency hidden.
+    float pbv[6];
+    auto pb_load = [&](int g, int m) {
+        const float *tr = tbuf + (g & 1) * 25 * FW;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) pbv[n] = tr[(5 * m + n) * FW + xn[n]];
+        if (m > 0) pbv[5] = accr[((g - m + 2) & (ACC_ROWS - 1)) * FW + xi];
+    };
+    auto pb_use = [&](int g, int m) {
+        float cm = pbv[0];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) cm += pbv[n];
+        const int y = g - m + 2;
+        const bool row_ok = (y >= ys) && (y < ye);
+        const float acc = (m == 0) ? cm : pbv[5] + cm;
+        if (m < 4) accr[(row_ok ? (y & (ACC_ROWS - 1)) : ACC_ROWS) * FW + xi] = acc;
+        else finalize(y, acc, row_ok && px_ok);
+    };
+
+    // Row loop.  Iteration f computes T row f (layers 1-3, 130 MFMA per wave) and,
+    // INSIDE that MFMA stream, folds T row f-1 (finished at the previous
+    // barrier) into the output accumulators; one extra iteration drains the
+    // last row.  One barrier per row.
+    const int f_end = (MODE == MODE_L12) ? f_hi - 1 : f_hi;
+    for (int f = f_lo; f <= f_end; ++f) {
+        unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
+        if constexpr (DIAG) dg_a = stamp();
+        const bool do_a = f < f_hi;
+        const int g = f - 1;
+        bool pb_fast = false;
+        if constexpr (MODE != MODE_L12) {
+            if (g >= f_lo) {
+                pb_fast = (g > 0) && (g < H - 1);
+                if (!pb_fast) pb_generic(g);
+            }
+        }
+        if (!do_a) {
+            if (pb_fast) {
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    pb_load(g, m);
+                    pb_use(g, m);
+                }
+            }
+            break;
+        }
+
         f32x16 d2;
         if constexpr (MODE != MODE_L3) {
             // prefetch the Y row the NEXT feature row needs
@@ -155,33 +271,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
             const float *ybN = yb + half;                    // taps 2s | 2s+1 in one row
             const float *ybW = yb + (half ? YP - 8 : 0);     // tap 2s = (ki,8), tap 2s+1 = (ki+1,0)
-            f32x16 a0 = {0}, a1 = {0};
-#pragma unroll
-            for (int s = 0; s < 41; ++s) {
+            auto ldb = [&](int s) -> float {
                 const int ki = (2 * s) / 9, kj = (2 * s) % 9;
-                float b;
-                if (s == 40)
-                    b = half ? 1.0f : yb[8 * YP + 8];        // tap 80 | bias tap
-                else if (kj == 8)
-                    b = ybW[ki * YP + kj];
-                else
-                    b = ybN[ki * YP + kj];
-                a0 = MFMA(w1f[0][s], b, a0);
-                a1 = MFMA(w1f[1][s], b, a1);
-            }
+                if (s == 40) return half ? 1.0f : yb[8 * YP + 8];   // tap 80 | bias tap
+                if (kj == 8) return ybW[ki * YP + kj];
+                return ybN[ki * YP + kj];
+            };
+            f32x16 a0 = {0}, a1 = {0};
+            auto layer1 = [&](auto with_pb) {
+                constexpr bool PB = decltype(with_pb)::value;
+                constexpr int PF = 3;                         // B operands read PF k-steps ahead
+                float bq[41];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a0[r] = fmaxf(a0[r], 0.f);
+                for (int s = 0; s < PF; ++s) bq[s] = ldb(s);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] = fmaxf(a1[r], 0.f);
+                for (int s = 0; s < 41; ++s) {
+                    if (s + PF < 41) bq[s + PF] = ldb(s + PF);
+                    if constexpr (PB && MODE != MODE_L12) {
+                        if (s % 8 == 1) pb_load(g, s / 8);
+                        if (s % 8 == 5) pb_use(g, s / 8);
+                    }
+                    a0 = MFMA(w1f[0][s], bq[s], a0);
+                    a1 = MFMA(w1f[1][s], bq[s], a1);
+                    // keep this k-step's LDS traffic / phase-B slice where it is
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (DIAG) dg_b = stamp();
+            if (pb_fast) layer1(std::true_type{});
+            else layer1(std::false_type{});
+            if constexpr (DIAG) dg_c = stamp();
+            // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
+            // dependent MFMAs breaks their back-to-back issue (~64 -> ~81 cycles per MFMA,
+            // tools/mfma_probe.hip), 32 of them up front cost ~140 cycles once.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[r] = relu(a0[r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[r] = relu(a1[r]);
+            __builtin_amdgcn_sched_barrier(0);
 
-            // ---------------- layer 2: 32 MFMA ------------------------------
+            // ---------------- layer 2: 32 MFMA, one back-to-back chain -------
             d2 = (f32x16){0};
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[r], a0[r], d2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[16 + r], a1[r], d2);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[r] = fmaxf(d2[r] + b2f[r], 0.f);
+            for (int r = 0; r < 16; ++r) d2[r] = relu(d2[r] + b2f[r]);
+            __builtin_amdgcn_sched_barrier(0);
 
             asm volatile("" : "+v"(ynext));
             if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
@@ -198,6 +336,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             const float *q = plf + (long)f * p.pl_stride;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[r] = q[(long)(2 * r + half) * p.pl_pitch];
+            if (pb_fast) {
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    pb_load(g, m);
+                    pb_use(g, m);
+                }
+            }
         }
 
         if constexpr (MODE != MODE_L12) {
@@ -205,68 +350,65 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             f32x16 t = {0};
 #pragma unroll
             for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
+            __builtin_amdgcn_sched_barrier(0);
             float *tb = tbuf + (f & 1) * 25 * FW + xi;
 #pragma unroll
             for (int r = 0; r < 12; ++r) tb[acc_row(r, 0) * FW + 4 * half * FW] = t[r];
             if (half == 0) tb[24 * FW] = t[12];
         }
 
+        if constexpr (DIAG) dg_d = stamp();
         __syncthreads();
-
-        if constexpr (MODE != MODE_L12) {
-            // ---------------- scatter-accumulate T row f ---------------------
-            // out(y,x) += c_m(x) for every (y,m) with clamp(y+m-2) == f, m ascending,
-            // c_m(x) = sum_n T[5m+n](f, clamp(x+n-2)).
-            if (half == 0) {
-                const float *tr = tbuf + (f & 1) * 25 * FW;
-                int xn[5];
-#pragma unroll
-                for (int n = 0; n < 5; ++n)
-                    xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
-                const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
-#pragma unroll
-                for (int m = 0; m < 5; ++m) {
-                    float cm = tr[(5 * m) * FW + xn[0]];
-#pragma unroll
-                    for (int n = 1; n < 5; ++n) cm += tr[(5 * m + n) * FW + xn[n]];
-                    int y0 = (f == 0) ? 0 : f - m + 2;
-                    int y1 = (f == H - 1) ? H - 1 : f - m + 2;
-                    y0 = max(y0, ys);
-                    y1 = min(y1, ye - 1);
-                    for (int y = y0; y <= y1; ++y) {
-                        float *ap = accr + (y & (ACC_ROWS - 1)) * FW + xi;
-                        const float acc = (m == 0) ? cm : *ap + cm;
-                        if (m < 4) {
-                            *ap = acc;
-                        } else if (px_ok) {
-                            const float v = acc + p.b3;
-                            const long o = (long)frame * p.dst_frame_pitch +
-                                           (long)(y - p.dst_row0) * p.dst_stride + gx;
-                            if (p.pre) p.pre[o] = v;
-                            // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240
-                            p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
-                        }
-                    }
-                }
-            }
+        if constexpr (DIAG) {
+            const unsigned long long e = stamp();
+            dg_top += dg_b - dg_a;
+            dg_l1 += dg_c - dg_b;
+            dg_l23 += dg_d - dg_c;
+            dg_bar += e - dg_d;
+        }
+    }
+    if constexpr (DIAG) {
+        const unsigned long long t1 = stamp();
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) +
+                                    ((long)blockIdx.x * NWAVES + wave) * 8;
+            o[0] = t1 - dg_t0;
+            o[1] = r1 - dg_r0;
+            o[2] = dg_top;
+            o[3] = dg_l1;
+            o[4] = dg_l23;
+            o[5] = dg_bar;
+            o[6] = (unsigned long long)(f_hi - f_lo);
+            o[7] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
         }
     }
 }
 
 size_t strip_lds_bytes(int /*mode*/)
 {
-    return sizeof(float) * (2 * YR * YP + 2 * 25 * FW + ACC_ROWS * FW);
+    return sizeof(float) * (2 * YR * YP + 2 * 25 * FW + (ACC_ROWS + 1) * FW);
 }
 
-hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream)
+hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
-    const size_t lds = strip_lds_bytes(mode);
+    const size_t lds = strip_lds_bytes(mode) + lds_pad;
+    const bool pre = p.pre != nullptr;
     switch (mode) {
-    case MODE_FUSED: hipLaunchKernelGGL(srcnn_strip_kernel<MODE_FUSED>, grid, block, lds, stream, p); break;
-    case MODE_L12:   hipLaunchKernelGGL(srcnn_strip_kernel<MODE_L12>, grid, block, lds, stream, p); break;
-    case MODE_L3:    hipLaunchKernelGGL(srcnn_strip_kernel<MODE_L3>, grid, block, lds, stream, p); break;
+    case MODE_FUSED:
+        if (p.tune & 2) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, true>), grid, block, lds, stream, p);
+        else if (pre) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false>), grid, block, lds, stream, p);
+        break;
+    case MODE_L12:
+        hipLaunchKernelGGL((srcnn_strip_kernel<MODE_L12, false>), grid, block, lds, stream, p);
+        break;
+    case MODE_L3:
+        if (pre) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_L3, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_L3, false>), grid, block, lds, stream, p);
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Diagnostics: run the fused kernel's DIAG build (SRCNN_DEBUG_TUNE=2) and print
+where a wave's cycles go and the in-kernel clock (s_memtime / s_memrealtime)."""
+import ctypes, os, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ["SRCNN_DEBUG_TUNE"] = os.environ.get("SRCNN_DEBUG_TUNE", "2")
+import numpy as np, torch
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_batch
+
+W, H = 3840, 2160
+ctx = S.Context(0); ctx.set_weights_blob(S.load_weights())
+d_in = torch.from_numpy(synth_batch(W, H, 1)).cuda(); d_out = torch.zeros_like(d_in)
+t0 = time.time()
+while time.time() - t0 < float(os.environ.get("WARM_S", "2.0")):      # hold the chip under load first
+    for _ in range(50):
+        ctx.forward_y_dev(d_in.data_ptr(), W, H * W, d_out.data_ptr(), W, H * W, W, H, 1)
+    ctx.synchronize()
+plan = ctx.query_plan(W, H, 1)
+n = plan["workgroups"] * 4
+buf = np.zeros(1 << 17, np.uint64)
+lib = S.load_library()
+lib.srcnn_debug_read_sink.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+assert lib.srcnn_debug_read_sink(ctx._h, buf.ctypes.data, buf.nbytes) == 0
+st = buf[128:128 + n * 8].reshape(n, 8).astype(np.float64)
+tot, real, top, l1, l23, bar, rows, hwid = st.T
+clk = tot / real * 100e6
+print(f"waves {n}  rows/wave {rows.mean():.1f}")
+print(f"in-kernel clock GHz: median {np.median(clk)/1e9:.3f}  min {clk.min()/1e9:.3f} max {clk.max()/1e9:.3f}")
+print(f"kernel cycles per wave: median {np.median(tot):.0f}  max {tot.max():.0f}  -> per row {np.median(tot/rows):.0f}")
+for name, v in [("top(loop head->L1)", top), ("L1 (82 MFMA + phase B)", l1), ("L2+L3+T write", l23), ("barrier wait", bar)]:
+    print(f"  {name:26s} per row: median {np.median(v/rows):8.0f}   mean {np.mean(v/rows):8.0f}")
+print("ideal MFMA cycles per row: L1 5248, L2+L3 3072, total 8320 (x2 waves per SIMD when 2 WG/CU)")
+slot = (hwid.astype(np.int64) & 0xF)
+for sl in np.unique(slot):
+    m = slot == sl
+    print(f"  wave slot {sl}: {m.sum()} waves, total cycles median {np.median(tot[m]):.0f}, L1/row {np.median((l1/rows)[m]):.0f}, bar/row {np.median((bar/rows)[m]):.0f}")
