@@ -1,0 +1,147 @@
+"""Multi-GPU decomposition of the SRCNN Y-channel path (one process per GPU).
+
+The reference has no distributed code; the path shards in
+two ways, both derived from its data dependences (src/srcnn.cpp:254-325,
+189-243: every output pixel depends on a 13x13 window of ONE input plane and on
+the constant weights):
+
+* independent planes (configs[2], configs[4]: batches / streams of frames):
+  contiguous frame ranges per rank, NO data-path collective --
+  ``frame_range()``;
+* one large plane (configs[3]): row stripes.  Each rank owns rows
+  [r0, r1) of the input; the fused kernel needs 6 more input rows on each
+  interior side (4 for the 9x9 layer + 2 for the 5x5 layer), so neighbours
+  swap exactly 6 luma rows (6*W bytes per boundary) point-to-point --
+  ``exchange_halo()`` -- and then run ``srcnn_forward_y_rows_dev`` on the
+  halo-extended stripe.  Exchanging 6 INPUT rows (46 KB at W=7680) instead of
+  2 rows of the 32-channel map (1.97 MB) keeps the layer-2 -> layer-3 hand-off
+  inside the fused kernel; image-edge rows are replicated as in the reference,
+  stripe-edge rows are real neighbour data.
+
+torch.distributed is plumbing only (NCCL == RCCL on ROCm for GPU tensors, gloo
+for the CPU tests).  The compute call is injected (``compute_rows``) so the
+CPU tests can drive this logic with the oracle; the product passes
+``Context.forward_y_rows_dev`` -- there is no CPU fallback in here.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+HALO_ROWS = 6   # 4 (9x9 layer) + 0 (1x1) + 2 (5x5 layer)
+
+
+def split_range(n: int, parts: int, index: int) -> Tuple[int, int]:
+    """Contiguous, balanced [begin, end) of `n` items for part `index` of `parts`
+    (the first n % parts parts get one extra item)."""
+    if parts <= 0 or not (0 <= index < parts) or n < 0:
+        raise ValueError("bad split")
+    base, extra = divmod(n, parts)
+    begin = index * base + min(index, extra)
+    return begin, begin + base + (1 if index < extra else 0)
+
+
+def frame_range(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
+    """Frames [begin, end) of a batch/stream handled by `rank` (no collective)."""
+    return split_range(n_frames, world, rank)
+
+
+def stripe_rows(height: int, world: int, rank: int) -> Tuple[int, int]:
+    """Output rows [r0, r1) of a single plane handled by `rank`."""
+    return split_range(height, world, rank)
+
+
+def halo_extent(height: int, r0: int, r1: int) -> Tuple[int, int]:
+    """Input rows [s0, s1) the fused kernel needs to produce output rows [r0, r1)."""
+    return max(0, r0 - HALO_ROWS), min(height, r1 + HALO_ROWS)
+
+
+def exchange_halo(stripe, height: int, world: int, rank: int, group=None):
+    """Swap HALO_ROWS input rows with the neighbouring ranks.
+
+    stripe : uint8 tensor [r1-r0, W] holding this rank's rows of the plane
+             (CPU tensor with gloo, GPU tensor with NCCL/RCCL).
+    Returns (ext, s0): tensor with rows [s0, s1) = stripe plus the neighbours'
+    halo rows; ranks owning fewer than HALO_ROWS rows are rejected (a halo would
+    span more than one neighbour).
+    """
+    import torch
+    import torch.distributed as dist
+
+    r0, r1 = stripe_rows(height, world, rank)
+    if stripe.shape[0] != r1 - r0:
+        raise ValueError(f"rank {rank}: stripe has {stripe.shape[0]} rows, owns [{r0},{r1})")
+    if world > 1 and min(stripe_rows(height, world, k)[1] - stripe_rows(height, world, k)[0]
+                         for k in range(world)) < HALO_ROWS:
+        raise ValueError("stripes thinner than the halo: use fewer ranks for this plane")
+    s0, s1 = halo_extent(height, r0, r1)
+    top_n, bot_n = r0 - s0, s1 - r1
+    width = stripe.shape[1]
+    ext = torch.empty((s1 - s0, width), dtype=stripe.dtype, device=stripe.device)
+    ext[top_n:top_n + (r1 - r0)] = stripe
+    ops = []
+    keep = []
+    if top_n:      # rank-1 exists: receive its last rows, send it my first rows
+        recv_top = ext[:top_n]
+        send_top = stripe[:HALO_ROWS].contiguous()
+        keep += [send_top]
+        ops += [dist.P2POp(dist.irecv, recv_top, rank - 1, group),
+                dist.P2POp(dist.isend, send_top, rank - 1, group)]
+    if bot_n:      # rank+1 exists
+        recv_bot = ext[top_n + (r1 - r0):]
+        send_bot = stripe[-HALO_ROWS:].contiguous()
+        keep += [send_bot]
+        ops += [dist.P2POp(dist.isend, send_bot, rank + 1, group),
+                dist.P2POp(dist.irecv, recv_bot, rank + 1, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return ext, s0
+
+
+def forward_striped(stripe, height: int, world: int, rank: int,
+                    compute_rows: Callable, group=None):
+    """Row-striped forward pass of ONE plane: halo exchange + one kernel launch.
+
+    compute_rows(ext, s0, out, r0, height, r0, r1) must fill `out`
+    (uint8 [r1-r0, W]) with output rows [r0, r1) given input rows starting at
+    image row s0 -- ``Context.forward_y_rows_dev`` semantics.
+    Returns this rank's output stripe.
+    """
+    import torch
+
+    r0, r1 = stripe_rows(height, world, rank)
+    ext, s0 = exchange_halo(stripe, height, world, rank, group)
+    out = torch.empty((r1 - r0, stripe.shape[1]), dtype=torch.uint8, device=stripe.device)
+    compute_rows(ext, s0, out, r0, height, r0, r1)
+    return out
+
+
+def gpu_compute_rows(ctx) -> Callable:
+    """compute_rows for GPU tensors through the C ABI (srcnn_forward_y_rows_dev)."""
+    def run(ext, s0, out, dst_row0, height, r0, r1):
+        if not ext.is_cuda:
+            raise RuntimeError("the HIP path needs device tensors (no CPU fallback)")
+        w = ext.shape[1]
+        ctx.forward_y_rows_dev(ext.data_ptr(), ext.stride(0), s0, out.data_ptr(), out.stride(0),
+                               dst_row0, w, height, r0, r1)
+        ctx.synchronize()
+    return run
+
+
+def gather_stripes(out, height: int, world: int, rank: int, dst: int = 0, group=None):
+    """Collect the output stripes on `dst` (verification / file output only; the
+    data path itself needs no collective).  Returns the full plane on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return out
+    sizes = [stripe_rows(height, world, k) for k in range(world)]
+    pad = max(b - a for a, b in sizes)
+    buf = torch.zeros((pad, out.shape[1]), dtype=out.dtype, device=out.device)
+    buf[:out.shape[0]] = out
+    gathered: Optional[List] = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, gathered, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([g[:b - a] for g, (a, b) in zip(gathered, sizes)], dim=0)

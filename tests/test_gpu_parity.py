@@ -304,3 +304,28 @@ def test_error_paths(gpu_ctx):
     with pytest.raises(S.SrcnnError):
         S.Context(99)
     ctx2.close()
+
+
+def test_cpp_host_through_reference_call_surface(tmp_path, weights_blob):
+    """A plain C++ host (tools/host_demo.cpp: no OpenCV, no HIP headers) calls
+    Convolution99x11 + Convolution55 with the reference's argument lists
+    (src/srcnn.cpp:609,627) and the fused ForwardY; both must give the plane the
+    FMA-order model predicts and sit within tolerance of the oracle."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "host_demo"
+    subprocess.run(["g++", "-std=c++17", f"-I{root / 'include'}", str(root / "tools" / "host_demo.cpp"),
+                    f"-L{root / 'srcnn_cpp_amd'}", "-lsrcnn_amd", f"-Wl,-rpath,{root / 'srcnn_cpp_amd'}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    w, h = 200, 45
+    out_file = tmp_path / "out.u8"
+    res = subprocess.run([str(exe), str(S._WEIGHTS_PATH), str(w), str(h), str(out_file)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    got = np.fromfile(out_file, np.uint8).reshape(h, w)
+    y = synth_luma(w, h)
+    m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert np.array_equal(got, m_out)
+    check_u8(got, r_out, r_pre)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-1 measurement sweep on ONE MI355X (run through gpurun); writes JSON lines.
+# usage: tools/measure_all.sh OUTFILE
+OUT=${1:-gpurun_out/measurements.jsonl}
+: > $OUT
+run() { echo "# $*" >> $OUT; python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $OUT; }
+run --steps 50                                                  # configs[1]: 1 x 3840x2160, fused
+run --steps 20 --path unfused                                   # same, materialising path
+run --steps 5 --frames 64                                       # configs[2]: 64 x 3840x2160, fused
+run --steps 3 --frames 64 --path unfused                        # configs[2], materialising im2col+MFMA path
+run --steps 20 --width 7680 --height 4320                       # configs[3] plane on one GPU
+run --steps 5 --width 5760 --height 3240 --frames 8             # configs[4] frames (8 of the 512) on one GPU
+run --steps 20 --width 576 --height 576                         # configs[0] plane on the GPU
+run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
+run --steps 5 --mode exact                                      # bit-exact VALU mode
+cat $OUT
