@@ -71,7 +71,15 @@ def main():
                     help="fused: one kernel, u8 in/out (default); unfused: layer-1/2 kernel -> 32 f32 planes in "
                          "HBM -> layer-3 kernel; host: srcnn_forward_y on pageable host buffers (PCIe-inclusive)")
     ap.add_argument("--mode", choices=["mfma", "exact"], default="mfma")
+    ap.add_argument("--workload", choices=["frames", "stripe"], default="frames",
+                    help="frames: independent planes per rank, no collective, weak scaling (default); "
+                         "stripe: ONE width x height plane row-striped over the ranks with a 6-row "
+                         "point-to-point halo exchange per step, strong scaling (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for the barrier / max-over-ranks (nccl == RCCL)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="smoke-test aid: every rank uses GPU 0 (1-GPU box, use with --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,12 +94,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     W, H, F = args.width, args.height, args.frames
     ctx = S.Context(local_rank)
@@ -104,7 +117,17 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     # each rank owns its frames (frame-sharded stream; no data-path collective)
-    frames = synth_batch(W, H, F, first_frame=rank * F)
+    stripe = args.workload == "stripe"
+    if stripe:
+        from srcnn_cpp_amd import sharding
+        from srcnn_cpp_amd.synth import synth_luma
+        if args.path != "fused" or F != 1:
+            raise SystemExit("--workload stripe runs the fused path on one plane")
+        r0, r1 = sharding.stripe_rows(H, world, rank)
+        frames = synth_luma(W, H)[None, r0:r1].copy()          # this rank's rows of the plane
+        compute_rows = sharding.gpu_compute_rows(ctx)
+    else:
+        frames = synth_batch(W, H, F, first_frame=rank * F)
     d_in = torch.from_numpy(frames).cuda()
     d_out = torch.zeros_like(d_in)
     d_work = torch.empty((F, 32, H, W), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
@@ -112,7 +135,14 @@ def main():
     host_out = np.empty_like(frames[0])
 
     def step():
-        if args.path == "host":
+        if stripe:
+            if world > 1 and args.backend == "gloo":            # smoke-test aid: halo over host memory
+                ext, s0 = sharding.exchange_halo(d_in[0].cpu(), H, world, rank)
+                ext = ext.cuda()
+            else:                                               # RCCL send/recv over xGMI
+                ext, s0 = sharding.exchange_halo(d_in[0], H, world, rank)
+            ctx.forward_y_rows_dev(ext.data_ptr(), ext.stride(0), s0, d_out.data_ptr(), W, r0, W, H, r0, r1)
+        elif args.path == "host":
             for k in range(F):
                 ctx.forward_y(frames[k], dst=host_out)
         elif args.path == "fused":
@@ -144,17 +174,17 @@ def main():
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sanity: the result of the last step is the real thing (bitwise == frame 0 recomputed)
-    chk = int(d_out[0, H // 2, : min(W, 4096)].to(torch.int64).sum().item())
+    chk = int(d_out[0, d_out.shape[1] // 2, : min(W, 4096)].to(torch.int64).sum().item())
 
     if rank == 0:
-        pix_per_step = W * H * F * world
+        pix_per_step = W * H if stripe else W * H * F * world
         value = pix_per_step * args.steps / elapsed / 1e6
-        flops_per_launch = S.FLOP_PER_PIXEL * W * H * F
+        flops_per_launch = S.FLOP_PER_PIXEL * W * (r1 - r0 if stripe else H * F)
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
         traffic = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
@@ -167,14 +197,15 @@ def main():
             "metric": "SRCNN Y-channel Mpixels/sec", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{F} x {W}x{H} luma plane per GPU per step "
-                                   + ("(1920x1080 x2.0, BASELINE configs[1]), " if (W, H, F) == (3840, 2160, 1) else "(custom shape), ")
+            "scaling": "strong" if stripe else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"ONE {W}x{H} luma plane row-striped over {world} GPU(s), 6-row halo exchange, "
+                                    if stripe else f"{F} x {W}x{H} luma plane per GPU per step ")
+                                   + ("(1920x1080 x2.0, BASELINE configs[1]), " if (W, H, F) == (3840, 2160, 1) and not stripe else "")
                                    + f"{args.path} conv path, {args.mode} "
                                    "arithmetic, " + ("host buffers over PCIe" if args.path == "host"
                                                      else "inputs resident in HBM"),
                        "frames_per_gpu": F, "width": W, "height": H, "path": args.path, "mode": args.mode,
-                       "plan": ctx.query_plan(W, H, F), "output_checksum": chk},
+                       "plan": ctx.query_plan(W, r1 - r0 if stripe else H, F), "output_checksum": chk},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4),

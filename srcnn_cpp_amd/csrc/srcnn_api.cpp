@@ -186,7 +186,13 @@ bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
     const int halo = (mode == MODE_L12) ? 0 : 2;
-    const Plan pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo);
+    Plan pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo);
+    static const char *env_segs = std::getenv("SRCNN_DEBUG_SEGS");     // experiment knob
+    if (env_segs && std::atoi(env_segs) > 0) {
+        const int rows = p.row_end - p.row_begin, ns = std::min(rows, std::atoi(env_segs));
+        pl.seg_rows = (rows + ns - 1) / ns;
+        pl.n_segs = (rows + pl.seg_rows - 1) / pl.seg_rows;
+    }
     p.seg_rows = pl.seg_rows;
     p.n_strips = pl.n_strips;
     p.n_segs = pl.n_segs;
