@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, unsigned long long *
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = b + r;
+    unsigned sacc = 0;
     const unsigned long long t0 = stamp();
     for (int it = 0; it < iters; ++it) {
         if constexpr (VARIANT == 0) {          // one dependent chain, 32 MFMA
@@ -123,8 +124,48 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, unsigned long long *
             asm volatile("" : "+v"(c2));
             v[0] += c2[0];
         }
+        else if constexpr (VARIANT == 12) {  // two chains + 12 SALU per pair
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c0 = MFMA(a, b, c0); c1 = MFMA(b, a, c1);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (VARIANT == 13) {  // two chains + 6 LDS reads (+1 wait) per pair
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c0 = MFMA(a, b, c0); c1 = MFMA(b, a, c1);
+                float x0 = lds[lane + 64 * (r & 7)], x1 = lds[lane + 1 + 64 * (r & 7)], x2 = lds[lane + 2 + 64 * (r & 7)];
+                float x3 = lds[lane + 3 + 64 * (r & 7)], x4 = lds[lane + 4 + 64 * (r & 7)], x5 = lds[lane + 5 + 64 * (r & 7)];
+                asm volatile("" :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (VARIANT == 14) {  // two chains + 6 v_pk_max_f32 per pair (12 registers)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c0 = MFMA(a, b, c0); c1 = MFMA(b, a, c1);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 t = {v[2 * q], v[2 * q + 1]};
+                    asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(t));
+                    v[2 * q] = t[0]; v[2 * q + 1] = t[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (VARIANT == 15) {  // two chains + 12 v_max_f32 per pair
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                c0 = MFMA(a, b, c0); c1 = MFMA(b, a, c1);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) asm volatile("v_max_f32 %0, 0, %0" : "+v"(v[q]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         asm volatile("" : "+v"(c0), "+v"(c1));
     }
+    asm volatile("" :: "s"(sacc));
     const unsigned long long t1 = stamp();
     float s = 0;
 #pragma unroll
@@ -160,6 +201,10 @@ int main()
     run<9>("two chains + 12 VALU per pair", 256, 256);
     run<10>("two chains, B from LDS 3 pairs ahead", 256, 256);
     run<11>("three chains + 4 VALU per triple", 256, 256);
+    run<12>("two chains + 12 SALU per pair", 256, 256);
+    run<13>("two chains + 6 LDS reads per pair", 256, 256);
+    run<14>("two chains + 6 v_pk_add (12 regs) per pair", 256, 256);
+    run<15>("two chains + 12 v_max per pair", 256, 256);
     run<0>("dependent chain, 2 waves/SIMD", 512, 256);
     run<1>("two interleaved chains, 2 waves/SIMD", 512, 256);
     run<2>("dependent chain, B from VALU, 2 waves/SIMD", 512, 256);
@@ -167,5 +212,9 @@ int main()
     run<5>("chain + 6 independent VALU, 2 waves/SIMD", 512, 256);
     run<9>("two chains + 12 VALU per pair, 2 waves/SIMD", 512, 256);
     run<10>("two chains, B from LDS, 2 waves/SIMD", 512, 256);
+    run<12>("two chains + 12 SALU per pair, 2 waves/SIMD", 512, 256);
+    run<13>("two chains + 6 LDS reads per pair, 2 waves/SIMD", 512, 256);
+    run<14>("two chains + 6 v_pk_add per pair, 2 waves/SIMD", 512, 256);
+    run<15>("two chains + 12 v_max per pair, 2 waves/SIMD", 512, 256);
     return 0;
 }
