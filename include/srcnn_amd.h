@@ -56,7 +56,7 @@ enum {
  *   SRCNN_MODE_EXACT reference arithmetic reproduced exactly on the vector
  *                    ALU (rounded multiply then rounded add, double 25-term
  *                    sums in layer 3): bit-identical to the reference CPU
- *                    path, roughly 4x slower. */
+ *                    path, roughly 11x slower (a verification mode). */
 enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1 };
 
 typedef struct srcnn_ctx srcnn_ctx;
@@ -156,6 +156,35 @@ int srcnn_conv99x11_dev(srcnn_ctx *ctx, const uint8_t *d_src, size_t src_stride,
 int srcnn_conv55_dev(srcnn_ctx *ctx, const float *d_planes, size_t plane_stride, size_t plane_pitch,
                      uint8_t *d_dst, size_t dst_stride, int width, int height,
                      float *d_preclamp /*may be NULL*/);
+
+/* ---- the steps either side of the path ---- *
+ * The reference delegates these to OpenCV (cvtColor, split/merge, resize):       *
+ * 8-bit integer arithmetic of OpenCV 4.x, restated in oracle/opencv_steps.c.     *
+ * Interleaved images are 3 bytes per pixel in B,G,R order (cv::imread), strides  *
+ * of interleaved images in BYTES per row.                                        */
+
+/* Output size of the reference pipeline: (int)(w*scale) x (int)(h*scale), src/srcnn.cpp:573-575. */
+int srcnn_scaled_size(int width, int height, float scale, int *out_w, int *out_h);
+
+/* cvtColor(CV_BGR2YCrCb) + split, src/srcnn.cpp:509,540. */
+int srcnn_bgr2ycrcb(srcnn_ctx *ctx, const uint8_t *bgr, size_t stride, int width, int height,
+                    uint8_t *y, uint8_t *cr, uint8_t *cb, size_t plane_stride);
+/* merge + cvtColor(CV_YCrCb2BGR), src/srcnn.cpp:639,657. */
+int srcnn_ycrcb2bgr(srcnn_ctx *ctx, const uint8_t *y, const uint8_t *cr, const uint8_t *cb,
+                    size_t plane_stride, int width, int height, uint8_t *bgr, size_t stride);
+/* resize(.., CV_INTER_CUBIC) of one 8-bit plane, src/srcnn.cpp:577-582. */
+int srcnn_resize_cubic(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride, int src_w, int src_h,
+                       uint8_t *dst, size_t dst_stride, int dst_w, int dst_h);
+
+/* The timed region of the reference's pipeline driver, src/srcnn.cpp:505-659, in one
+ * call: BGR -> YCrCb, bicubic x scale on the three planes, SRCNN on Y, YCrCb -> BGR.
+ * `out` is srcnn_scaled_size() pixels; needs srcnn_set_weights.  The shape of the
+ * sibling library's ProcessSRCNN(rgb, w, h, d, scale, out, outsz) (src/test.cpp:347-353). */
+int srcnn_process_bgr(srcnn_ctx *ctx, const uint8_t *bgr, size_t stride, int width, int height,
+                      float scale, uint8_t *out, size_t out_stride);
+/* Same on device memory, asynchronous on the context's stream. */
+int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, int width, int height,
+                          float scale, uint8_t *d_out, size_t out_stride);
 
 /* ---- introspection for the bench / tests ---------------------------------- */
 

@@ -158,5 +158,26 @@ inline void ForwardY(MatU8 &src, MatU8 &dst, const float kernel99[64][9][9], con
                             src.rows, nullptr, 0));
 }
 
+// The timed region of the reference's pipeline driver (src/srcnn.cpp:505-659) with the
+// buffer-level shape of the sibling library's ProcessSRCNN (src/test.cpp:347-353):
+// packed B,G,R bytes in, packed B,G,R bytes out at (int)(w*scale) x (int)(h*scale).
+// Returns 0 and fills out/out_w/out_h; needs a model (pass the convdata.h tables).
+inline int ProcessSRCNN(const unsigned char *bgr, unsigned w, unsigned h, float scale,
+                        std::vector<unsigned char> &out, unsigned &out_w, unsigned &out_h,
+                        const float kernel99[64][9][9], const float bias99[64], const float kernel11[32][64],
+                        const float bias11[32], const float kernel55[32][5][5], float bias55)
+{
+    int ow = 0, oh = 0;
+    if (!bgr || srcnn_scaled_size((int)w, (int)h, scale, &ow, &oh) != SRCNN_OK) return SRCNN_ERR_INVALID;
+    Session &s = Session::thread_default();
+    int rc = srcnn_set_weights(s.get(), &kernel99[0][0][0], bias99, &kernel11[0][0], bias11, &kernel55[0][0][0], bias55);
+    if (rc != SRCNN_OK) return rc;
+    out.assign((std::size_t)ow * oh * 3, 0);
+    rc = srcnn_process_bgr(s.get(), bgr, 3 * (std::size_t)w, (int)w, (int)h, scale, out.data(), 3 * (std::size_t)ow);
+    out_w = (unsigned)ow;
+    out_h = (unsigned)oh;
+    return rc;
+}
+
 }  // namespace srcnn
 #endif  // SRCNN_AMD_HPP

@@ -41,7 +41,7 @@ def _cpu_has(*flags: str) -> bool:
 
 def build(force: bool = False) -> Path:
     """(Re)build liboracle with oracle/Makefile; generic x86-64 if no AVX2/FMA."""
-    srcs = [_HERE / "srcnn_oracle.c", _HERE / "srcnn_gpuorder.c", _HERE / "Makefile"]
+    srcs = [_HERE / "srcnn_oracle.c", _HERE / "srcnn_gpuorder.c", _HERE / "opencv_steps.c", _HERE / "Makefile"]
     stale = (not _LIB_PATH.exists()) or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
         arch = "-mavx2 -mfma" if _cpu_has("avx2", "fma") else ""
@@ -69,8 +69,10 @@ def lib() -> C.CDLL:
             getattr(_lib, name).argtypes = [_u8p, sz, pp, sz, i, i, _f32p, _f32p, _f32p, _f32p]
         for name in ("srcnn_oracle_forward_y", "srcnn_gpuorder_forward_y"):
             getattr(_lib, name).argtypes = [_u8p, sz, _u8p, sz, i, i, _f32p, _f32p]
-        for name in dir(_lib):
-            pass
+        _lib.opencv_bgr2ycrcb.argtypes = [_u8p, sz, i, i, _u8p, _u8p, _u8p, sz]
+        _lib.opencv_ycrcb2bgr.argtypes = [_u8p, _u8p, _u8p, sz, i, i, _u8p, sz]
+        _lib.opencv_resize_cubic.argtypes = [_u8p, sz, i, i, _u8p, sz, i, i]
+        _lib.opencv_scaled_dim.argtypes = [i, C.c_float]
     return _lib
 
 
@@ -193,3 +195,47 @@ def forward_y(src, blob):
 
 def gpuorder_forward_y(src, blob):
     return _forward(lib().srcnn_gpuorder_forward_y, src, blob)
+
+
+# ---- the OpenCV steps either side of the conv path (oracle/opencv_steps.c; UNPINNED third-party arithmetic)
+
+def bgr2ycrcb(bgr):
+    bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+    h, w, _ = bgr.shape
+    out = [np.empty((h, w), np.uint8) for _ in range(3)]
+    rc = lib().opencv_bgr2ycrcb(bgr.ctypes.data_as(_u8p), 3 * w, w, h, *[o.ctypes.data_as(_u8p) for o in out], w)
+    assert rc == 0
+    return out
+
+
+def ycrcb2bgr(y, cr, cb):
+    planes = [np.ascontiguousarray(p, dtype=np.uint8) for p in (y, cr, cb)]
+    h, w = planes[0].shape
+    out = np.empty((h, w, 3), np.uint8)
+    rc = lib().opencv_ycrcb2bgr(*[p.ctypes.data_as(_u8p) for p in planes], w, w, h, out.ctypes.data_as(_u8p), 3 * w)
+    assert rc == 0
+    return out
+
+
+def resize_cubic(src, dst_w, dst_h):
+    src, ps = _u8(src)
+    h, w = src.shape
+    out = np.empty((dst_h, dst_w), np.uint8)
+    rc = lib().opencv_resize_cubic(ps, w, w, h, out.ctypes.data_as(_u8p), dst_w, dst_w, dst_h)
+    assert rc == 0
+    return out
+
+
+def scaled_size(w, h, scale):
+    return lib().opencv_scaled_dim(w, float(scale)), lib().opencv_scaled_dim(h, float(scale))
+
+
+def process_bgr(bgr, scale, blob, y_path=None):
+    """The reference's timed pipeline region (src/srcnn.cpp:505-659) on the CPU:
+    colour conversion, 3 x bicubic, conv path on Y (``y_path`` defaults to the
+    reference arithmetic ``forward_y``), conversion back."""
+    h, w, _ = bgr.shape
+    ow, oh = scaled_size(w, h, scale)
+    planes = [resize_cubic(p, ow, oh) for p in bgr2ycrcb(bgr)]
+    y_sr, _ = (y_path or forward_y)(planes[0], blob)
+    return ycrcb2bgr(y_sr, planes[1], planes[2])

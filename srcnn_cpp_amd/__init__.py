@@ -99,6 +99,12 @@ def load_library() -> C.CDLL:
         "srcnn_conv99x11_dev": ([vp, vp, sz, vp, sz, sz, i, i], i),
         "srcnn_conv55_dev": ([vp, vp, sz, sz, vp, sz, i, i, vp], i),
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
+        "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
+        "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
+        "srcnn_ycrcb2bgr": ([vp, _u8p, _u8p, _u8p, sz, i, i, _u8p, sz], i),
+        "srcnn_resize_cubic": ([vp, _u8p, sz, i, i, _u8p, sz, i, i], i),
+        "srcnn_process_bgr": ([vp, _u8p, sz, i, i, C.c_float, _u8p, sz], i),
+        "srcnn_process_bgr_dev": ([vp, vp, sz, i, i, C.c_float, vp, sz], i),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
@@ -113,7 +119,8 @@ ABI_SYMBOLS = (
     "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_conv99", "srcnn_conv11",
     "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
-    "srcnn_conv55_dev", "srcnn_query_plan",
+    "srcnn_conv55_dev", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
 )
 
 
@@ -299,6 +306,81 @@ class Context:
                    d_preclamp=0):
         self._check(self._lib.srcnn_conv55_dev(self._h, d_planes, plane_stride, plane_pitch, d_dst,
                                                dst_stride, width, height, d_preclamp or None))
+
+
+def scaled_size(width: int, height: int, scale: float):
+    """(int)(w*scale), (int)(h*scale) -- src/srcnn.cpp:573-575."""
+    ow, oh = C.c_int(), C.c_int()
+    rc = load_library().srcnn_scaled_size(width, height, float(scale), C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise SrcnnError(rc, "scale too small")
+    return ow.value, oh.value
+
+
+def _image(a, name, writable=False):
+    if not isinstance(a, np.ndarray) or a.ndim != 3 or a.shape[2] != 3 or a.dtype != np.uint8:
+        raise TypeError(f"{name}: expected an HxWx3 uint8 array (B,G,R)")
+    if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 3 * a.shape[1]:
+        raise ValueError(f"{name}: pixels must be packed B,G,R (row stride may be padded)")
+    if writable and not a.flags.writeable:
+        raise ValueError(f"{name}: output image is read-only")
+    return a, a.strides[0]
+
+
+def _ctx_method(fn):
+    setattr(Context, fn.__name__, fn)
+    return fn
+
+
+@_ctx_method
+def bgr2ycrcb(self, bgr):
+    """cvtColor(CV_BGR2YCrCb) + split (src/srcnn.cpp:509,540) -> (y, cr, cb) planes."""
+    bgr, st = _image(bgr, "bgr")
+    h, w, _ = bgr.shape
+    out = [np.empty((h, w), np.uint8) for _ in range(3)]
+    self._check(self._lib.srcnn_bgr2ycrcb(self._h, bgr.ctypes.data_as(_u8p), st, w, h,
+                                          *[o.ctypes.data_as(_u8p) for o in out], w))
+    return out
+
+
+@_ctx_method
+def ycrcb2bgr(self, y, cr, cb):
+    """merge + cvtColor(CV_YCrCb2BGR) (src/srcnn.cpp:639,657) -> HxWx3 B,G,R."""
+    planes = [np.ascontiguousarray(p, dtype=np.uint8) for p in (y, cr, cb)]
+    h, w = planes[0].shape
+    out = np.empty((h, w, 3), np.uint8)
+    self._check(self._lib.srcnn_ycrcb2bgr(self._h, *[p.ctypes.data_as(_u8p) for p in planes], w, w, h,
+                                          out.ctypes.data_as(_u8p), 3 * w))
+    return out
+
+
+@_ctx_method
+def resize_cubic(self, src, dst_w, dst_h):
+    """resize(.., CV_INTER_CUBIC) of one 8-bit plane (src/srcnn.cpp:577-582)."""
+    src, ss = _plane(src, np.uint8, "src")
+    h, w = src.shape
+    out = np.empty((dst_h, dst_w), np.uint8)
+    self._check(self._lib.srcnn_resize_cubic(self._h, src.ctypes.data_as(_u8p), ss, w, h,
+                                             out.ctypes.data_as(_u8p), dst_w, dst_w, dst_h))
+    return out
+
+
+@_ctx_method
+def process_bgr(self, bgr, scale):
+    """The reference's timed pipeline region (src/srcnn.cpp:505-659) in one call."""
+    bgr, st = _image(bgr, "bgr")
+    h, w, _ = bgr.shape
+    ow, oh = scaled_size(w, h, scale)
+    out = np.empty((oh, ow, 3), np.uint8)
+    self._check(self._lib.srcnn_process_bgr(self._h, bgr.ctypes.data_as(_u8p), st, w, h, float(scale),
+                                            out.ctypes.data_as(_u8p), 3 * ow))
+    return out
+
+
+@_ctx_method
+def process_bgr_dev(self, d_bgr, stride, width, height, scale, d_out, out_stride):
+    self._check(self._lib.srcnn_process_bgr_dev(self._h, d_bgr, stride, width, height, float(scale),
+                                                d_out, out_stride))
 
 
 _default: Optional[Context] = None

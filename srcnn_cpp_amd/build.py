@@ -23,6 +23,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno
 UNITS = [
     ("srcnn_mfma.hip", []),
     ("srcnn_exact.hip", ["-ffp-contract=off"]),
+    ("srcnn_pipeline.hip", []),
     ("srcnn_api.cpp", ["-x", "hip"]),
 ]
 

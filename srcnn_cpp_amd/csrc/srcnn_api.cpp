@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,6 +43,8 @@ struct srcnn_ctx {
     DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
     // staging for the host-buffer entry points
     DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
+    // pipeline steps around the conv path
+    DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
 };
 
 namespace {
@@ -208,6 +211,75 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     return SRCNN_OK;
 }
 
+
+// Keys cubic (A = -0.75) coefficient table of one axis in OpenCV's 11-bit fixed point:
+// ofs[d] = floor((d + 0.5) * n_src / n_dst - 0.5), coef[d][0..3] = round(2048 * w_k(frac)).
+// Float arithmetic in exactly this order (no contraction): cv::resize INTER_CUBIC, 8-bit path.
+#pragma clang fp contract(off)
+void cubic_table(int n_src, int n_dst, int *ofs, short *coef)
+{
+    const double scale = 1.0 / ((double)n_dst / n_src);
+    const float A = -0.75f;
+    for (int d = 0; d < n_dst; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        const int sx = (int)std::floor(fx);
+        fx -= sx;
+        float cf[4];
+        cf[0] = ((A * (fx + 1) - 5 * A) * (fx + 1) + 8 * A) * (fx + 1) - 4 * A;
+        cf[1] = ((A + 2) * fx - (A + 3)) * fx * fx + 1;
+        cf[2] = ((A + 2) * (1 - fx) - (A + 3)) * (1 - fx) * (1 - fx) + 1;
+        cf[3] = 1.f - cf[0] - cf[1] - cf[2];
+        ofs[d] = sx;
+        for (int k = 0; k < 4; ++k) {
+            const long q = std::lrintf(cf[k] * 2048.f);
+            coef[4 * d + k] = (short)std::min(32767L, std::max(-32768L, q));
+        }
+    }
+}
+
+// Device-side cubic resize of n_planes planes; tables are built on the host and uploaded.
+int resize_planes_dev(srcnn_ctx *c, const uint8_t *src, long sstride, long spitch, int sw, int sh, uint8_t *dst,
+                      long dstride, long dpitch, int dw, int dh, int n_planes)
+{
+    const size_t ints = (size_t)dw + dh, shorts = 4 * ((size_t)dw + dh);
+    const size_t bytes = ints * 4 + shorts * 2;
+    std::vector<unsigned char> host(bytes);
+    int *xofs = reinterpret_cast<int *>(host.data()), *yofs = xofs + dw;
+    short *alpha = reinterpret_cast<short *>(yofs + dh), *beta = alpha + 4 * (size_t)dw;
+    cubic_table(sw, dw, xofs, alpha);
+    cubic_table(sh, dh, yofs, beta);
+    int rc;
+    if ((rc = reserve(c, c->tables, bytes))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // the previous launch may still read the tables
+    HIP_TRY(c, hipMemcpy(c->tables.p, host.data(), bytes, hipMemcpyHostToDevice));
+    const int *dx = static_cast<const int *>(c->tables.p), *dy = dx + dw;
+    const short *da = reinterpret_cast<const short *>(dy + dh), *db = da + 4 * (size_t)dw;
+    HIP_TRY(c, launch_resize_cubic(src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, n_planes, dx, da, dy,
+                                   db, c->stream));
+    return SRCNN_OK;
+}
+
+// The timed region of the reference's pipeline driver (src/srcnn.cpp:505-659) on device memory.
+int process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int w, int h, float scale, uint8_t *d_out,
+                    size_t out_stride)
+{
+    const int ow = (int)((float)w * scale), oh = (int)((float)h * scale);    // src/srcnn.cpp:573-575
+    if (ow <= 0 || oh <= 0) return fail(c, SRCNN_ERR_INVALID, "scale too small");   // :485-495
+    const size_t lo = (size_t)w * h, hi = (size_t)ow * oh;
+    int rc;
+    if ((rc = reserve(c, c->ycc_lo, 3 * lo))) return rc;
+    if ((rc = reserve(c, c->ycc_hi, 3 * hi))) return rc;
+    if ((rc = reserve(c, c->y_sr, hi))) return rc;
+    uint8_t *ycc_lo = static_cast<uint8_t *>(c->ycc_lo.p), *ycc_hi = static_cast<uint8_t *>(c->ycc_hi.p);
+    uint8_t *y_sr = static_cast<uint8_t *>(c->y_sr.p);
+    HIP_TRY(c, launch_bgr2ycrcb(d_bgr, (long)stride, w, h, ycc_lo, w, (long)lo, c->stream));      // :509, :540
+    if ((rc = resize_planes_dev(c, ycc_lo, w, (long)lo, w, h, ycc_hi, ow, (long)hi, ow, oh, 3))) return rc;  // :568-583
+    if ((rc = srcnn_forward_y_dev(c, ycc_hi, ow, hi, y_sr, ow, hi, ow, oh, 1, nullptr))) return rc;           // :609, :627
+    HIP_TRY(c, launch_ycrcb2bgr(y_sr, ow, ycc_hi + hi, ow, (long)hi, ow, oh, d_out, (long)out_stride,
+                                c->stream));                                                      // :638-657
+    return SRCNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -242,7 +314,8 @@ void srcnn_destroy(srcnn_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink})
+    for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
+                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables})
         release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -623,6 +696,120 @@ int srcnn_conv11(srcnn_ctx *c, const float *const *src, size_t src_stride, float
                                    static_cast<float *>(c->plane1.p), width, width, height,
                                    static_cast<float *>(c->kern.p), bias, c->stream));
     HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride * 4, c->plane1.p, (size_t)width * 4, (size_t)width * 4, height,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+/* ------------------------- pipeline steps around the conv path ------------- */
+
+int srcnn_scaled_size(int width, int height, float scale, int *out_w, int *out_h)
+{
+    if (!out_w || !out_h || width <= 0 || height <= 0) return SRCNN_ERR_INVALID;
+    *out_w = (int)((float)width * scale);
+    *out_h = (int)((float)height * scale);
+    return (*out_w > 0 && *out_h > 0) ? SRCNN_OK : SRCNN_ERR_INVALID;
+}
+
+int srcnn_bgr2ycrcb(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width, int height, uint8_t *y,
+                    uint8_t *cr, uint8_t *cb, size_t plane_stride)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!bgr || !y || !cr || !cb || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
+        plane_stride < (size_t)width)
+        return fail(c, SRCNN_ERR_INVALID, "bgr2ycrcb: bad arguments");
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->bgr_in, 3 * n))) return rc;
+    if ((rc = reserve(c, c->ycc_lo, 3 * n))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->bgr_in.p, 3 * (size_t)width, bgr, stride, 3 * (size_t)width, height,
+                                hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_bgr2ycrcb(static_cast<uint8_t *>(c->bgr_in.p), 3L * width, width, height,
+                                static_cast<uint8_t *>(c->ycc_lo.p), width, (long)n, c->stream));
+    uint8_t *outs[3] = {y, cr, cb};
+    for (int k = 0; k < 3; ++k)
+        HIP_TRY(c, hipMemcpy2DAsync(outs[k], plane_stride, static_cast<uint8_t *>(c->ycc_lo.p) + n * k, width, width,
+                                    height, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_ycrcb2bgr(srcnn_ctx *c, const uint8_t *y, const uint8_t *cr, const uint8_t *cb, size_t plane_stride,
+                    int width, int height, uint8_t *bgr, size_t stride)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!bgr || !y || !cr || !cb || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
+        plane_stride < (size_t)width)
+        return fail(c, SRCNN_ERR_INVALID, "ycrcb2bgr: bad arguments");
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->bgr_out, 3 * n))) return rc;
+    if ((rc = reserve(c, c->ycc_hi, 3 * n))) return rc;
+    const uint8_t *ins[3] = {y, cr, cb};
+    for (int k = 0; k < 3; ++k)
+        HIP_TRY(c, hipMemcpy2DAsync(static_cast<uint8_t *>(c->ycc_hi.p) + n * k, width, ins[k], plane_stride, width,
+                                    height, hipMemcpyHostToDevice, c->stream));
+    uint8_t *p = static_cast<uint8_t *>(c->ycc_hi.p);
+    HIP_TRY(c, launch_ycrcb2bgr(p, width, p + n, width, (long)n, width, height,
+                                static_cast<uint8_t *>(c->bgr_out.p), 3L * width, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(bgr, stride, c->bgr_out.p, 3 * (size_t)width, 3 * (size_t)width, height,
+                                hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_resize_cubic(srcnn_ctx *c, const uint8_t *src, size_t src_stride, int src_w, int src_h, uint8_t *dst,
+                       size_t dst_stride, int dst_w, int dst_h)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (bad_plane(src, src_stride, src_w, src_h) || bad_plane(dst, dst_stride, dst_w, dst_h))
+        return fail(c, SRCNN_ERR_INVALID, "resize_cubic: bad arguments");
+    const size_t ns = (size_t)src_w * src_h, nd = (size_t)dst_w * dst_h;
+    if ((rc = reserve(c, c->ycc_lo, ns))) return rc;
+    if ((rc = reserve(c, c->ycc_hi, nd))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->ycc_lo.p, src_w, src, src_stride, src_w, src_h, hipMemcpyHostToDevice,
+                                c->stream));
+    if ((rc = resize_planes_dev(c, static_cast<uint8_t *>(c->ycc_lo.p), src_w, (long)ns, src_w, src_h,
+                                static_cast<uint8_t *>(c->ycc_hi.p), dst_w, (long)nd, dst_w, dst_h, 1)))
+        return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->ycc_hi.p, dst_w, dst_w, dst_h, hipMemcpyDeviceToHost,
+                                c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+int srcnn_process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int width, int height, float scale,
+                          uint8_t *d_out, size_t out_stride)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    int ow = 0, oh = 0;
+    if (!d_bgr || !d_out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
+        srcnn_scaled_size(width, height, scale, &ow, &oh) != SRCNN_OK || out_stride < 3 * (size_t)ow)
+        return fail(c, SRCNN_ERR_INVALID, "process_bgr_dev: bad arguments");
+    return process_bgr_dev(c, d_bgr, stride, width, height, scale, d_out, out_stride);
+}
+
+int srcnn_process_bgr(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width, int height, float scale,
+                      uint8_t *out, size_t out_stride)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    int ow = 0, oh = 0;
+    if (!bgr || !out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
+        srcnn_scaled_size(width, height, scale, &ow, &oh) != SRCNN_OK || out_stride < 3 * (size_t)ow)
+        return fail(c, SRCNN_ERR_INVALID, "process_bgr: bad arguments");
+    if ((rc = reserve(c, c->bgr_in, 3 * (size_t)width * height))) return rc;
+    if ((rc = reserve(c, c->bgr_out, 3 * (size_t)ow * oh))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->bgr_in.p, 3 * (size_t)width, bgr, stride, 3 * (size_t)width, height,
+                                hipMemcpyHostToDevice, c->stream));
+    if ((rc = process_bgr_dev(c, static_cast<uint8_t *>(c->bgr_in.p), 3 * (size_t)width, width, height, scale,
+                              static_cast<uint8_t *>(c->bgr_out.p), 3 * (size_t)ow)))
+        return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(out, out_stride, c->bgr_out.p, 3 * (size_t)ow, 3 * (size_t)ow, oh,
                                 hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SRCNN_OK;

@@ -70,4 +70,13 @@ hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, lon
                                int w, int h, int n_frames, const float *d_kernel800, float bias,
                                hipStream_t st);
 
+// ---- pipeline steps around the conv path (srcnn_pipeline.hip) ---------------
+hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,
+                            long ppitch, hipStream_t st);
+hipError_t launch_ycrcb2bgr(const uint8_t *y, long ystride, const uint8_t *crcb, long pstride, long ppitch, int w,
+                            int h, uint8_t *bgr, long stride, hipStream_t st);
+hipError_t launch_resize_cubic(const uint8_t *src, long sstride, long spitch, int sw, int sh, uint8_t *dst,
+                               long dstride, long dpitch, int dw, int dh, int n_planes, const int *xofs,
+                               const short *alpha, const int *yofs, const short *beta, hipStream_t st);
+
 }  // namespace srcnn

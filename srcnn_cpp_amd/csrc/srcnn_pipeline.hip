@@ -1,0 +1,103 @@
+// srcnn_pipeline.hip -- the steps either side of the conv path in the
+// reference's pipeline driver, as HBM-bound
+// byte kernels:
+//   cvtColor BGR->YCrCb + split     src/srcnn.cpp:509,540
+//   resize INTER_CUBIC (3 planes)   src/srcnn.cpp:568-583
+//   merge + cvtColor YCrCb->BGR     src/srcnn.cpp:639,657
+// The arithmetic is OpenCV 4.x's 8-bit integer definition (fixed-point colour
+// coefficients, 11-bit cubic coefficients, (sum + 2^21) >> 22), restated in
+// oracle/opencv_steps.c; it is integer work, so the kernels are bit-exact
+// against that restatement.  One byte in, one byte out per element: no reuse,
+// no LDS, consecutive lanes on consecutive bytes.
+#include "srcnn_kernels.h"
+
+namespace srcnn {
+
+__device__ __forceinline__ int descale14(int x) { return (x + (1 << 13)) >> 14; }
+__device__ __forceinline__ uint8_t sat8(int v) { return (uint8_t)min(max(v, 0), 255); }
+
+__global__ __launch_bounds__(256) void bgr2ycrcb_kernel(const uint8_t *__restrict__ bgr, long stride, int w, int h,
+                                                        uint8_t *__restrict__ planes, long pstride, long ppitch)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= w || r >= h) return;
+    const uint8_t *p = bgr + (long)r * stride + 3L * c;
+    const int B = p[0], G = p[1], R = p[2];
+    const int Y = descale14(B * 1868 + G * 9617 + R * 4899);
+    const long o = (long)r * pstride + c;
+    planes[o] = sat8(Y);
+    planes[ppitch + o] = sat8(descale14((R - Y) * 11682 + (128 << 14)));
+    planes[2 * ppitch + o] = sat8(descale14((B - Y) * 9241 + (128 << 14)));
+}
+
+__global__ __launch_bounds__(256) void ycrcb2bgr_kernel(const uint8_t *__restrict__ yp, long ystride,
+                                                        const uint8_t *__restrict__ crcb, long pstride, long ppitch,
+                                                        int w, int h, uint8_t *__restrict__ bgr, long stride)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= w || r >= h) return;
+    const int Y = yp[(long)r * ystride + c];
+    const long o = (long)r * pstride + c;
+    const int Cr = crcb[o] - 128, Cb = crcb[ppitch + o] - 128;
+    uint8_t *p = bgr + (long)r * stride + 3L * c;
+    p[0] = sat8(Y + descale14(Cb * 29049));
+    p[1] = sat8(Y + descale14(Cb * -5636 + Cr * -11698));
+    p[2] = sat8(Y + descale14(Cr * 22987));
+}
+
+// dst(dy,dx) = sat(( sum_ky beta[dy][ky] * sum_kx alpha[dx][kx] * src[clamp(yofs[dy]-1+ky)][clamp(xofs[dx]-1+kx)]
+//                    + 2^21 ) >> 22);   blockIdx.z = plane
+__global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t *__restrict__ src, long sstride, long spitch,
+                                                           int sw, int sh, uint8_t *__restrict__ dst, long dstride,
+                                                           long dpitch, int dw, int dh,
+                                                           const int *__restrict__ xofs, const short *__restrict__ alpha,
+                                                           const int *__restrict__ yofs, const short *__restrict__ beta)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw || dy >= dh) return;
+    const uint8_t *s = src + (long)blockIdx.z * spitch;
+    const int x0 = xofs[dx] - 1, y0 = yofs[dy] - 1;
+    int a[4], xs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = alpha[4 * dx + k];
+        xs[k] = min(max(x0 + k, 0), sw - 1);
+    }
+    int acc = 0;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        const uint8_t *row = s + (long)min(max(y0 + ky, 0), sh - 1) * sstride;
+        int t = 0;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) t += row[xs[kx]] * a[kx];
+        acc += t * (int)beta[4 * dy + ky];
+    }
+    dst[(long)blockIdx.z * dpitch + (long)dy * dstride + dx] = sat8((acc + (1 << 21)) >> 22);
+}
+
+hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,
+                            long ppitch, hipStream_t st)
+{
+    hipLaunchKernelGGL(bgr2ycrcb_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, bgr, stride, w, h, planes,
+                       pstride, ppitch);
+    return hipGetLastError();
+}
+
+hipError_t launch_ycrcb2bgr(const uint8_t *y, long ystride, const uint8_t *crcb, long pstride, long ppitch, int w,
+                            int h, uint8_t *bgr, long stride, hipStream_t st)
+{
+    hipLaunchKernelGGL(ycrcb2bgr_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, y, ystride, crcb, pstride,
+                       ppitch, w, h, bgr, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_cubic(const uint8_t *src, long sstride, long spitch, int sw, int sh, uint8_t *dst,
+                               long dstride, long dpitch, int dw, int dh, int n_planes, const int *xofs,
+                               const short *alpha, const int *yofs, const short *beta, hipStream_t st)
+{
+    hipLaunchKernelGGL(resize_cubic_kernel, dim3((dw + 255) / 256, dh, n_planes), dim3(256), 0, st, src, sstride,
+                       spitch, sw, sh, dst, dstride, dpitch, dw, dh, xofs, alpha, yofs, beta);
+    return hipGetLastError();
+}
+
+}  // namespace srcnn

@@ -18,7 +18,15 @@ reference tree on the GPU box:
                            resize (neither is in /root/reference: un-pinned
                            third-party arithmetic), hence a PSNR pin, not bits.
 
-Both are 576*576 bytes, row-major.  Only data is committed; no reference source.
+Both are 576*576 bytes, row-major.
+
+  butterfly_bgr.npz        src_bgr [384,384,3] = butterfly.png, ref_bgr [576,576,3] =
+                           butterfly-srcnn.png, both as cv::imread would hand them
+                           over (B,G,R byte order).  Input and expected output of
+                           the WHOLE pipeline region src/srcnn.cpp:505-659 at
+                           --scale=1.5: the strongest pin the reference offers.
+
+Only data is committed; no reference source.
 """
 import sys
 from pathlib import Path
@@ -72,6 +80,7 @@ def main():
     y_in = bicubic_cv(luma_cv(src), 1.5)
     y_ref = luma_cv(ref)
     assert y_in.shape == y_ref.shape == (576, 576)
+    np.savez_compressed(OUT / "butterfly_bgr.npz", src_bgr=src[:, :, ::-1].copy(), ref_bgr=ref[:, :, ::-1].copy())
     y_in.tofile(OUT / "butterfly_y_in_576.u8")
     y_ref.tofile(OUT / "butterfly_y_ref_576.u8")
     print("wrote", y_in.shape, y_ref.shape)
