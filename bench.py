@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames", type=int, default=1, help="frames per GPU per step")
-    ap.add_argument("--path", choices=["fused", "unfused", "host"], default="fused",
+    ap.add_argument("--path", choices=["fused", "unfused", "host", "pipeline"], default="fused",
                     help="fused: one kernel, u8 in/out (default); unfused: layer-1/2 kernel -> 32 f32 planes in "
                          "HBM -> layer-3 kernel; host: srcnn_forward_y on pageable host buffers (PCIe-inclusive)")
     ap.add_argument("--mode", choices=["mfma", "exact"], default="mfma")
@@ -133,6 +133,12 @@ def main():
     d_work = torch.empty((F, 32, H, W), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
 
     host_out = np.empty_like(frames[0])
+    if args.path == "pipeline":
+        if W % 2 or H % 2 or stripe:
+            raise SystemExit("--path pipeline upsamples x2: width and height must be even")
+        lo = np.stack([frames[:, ::2, ::2]] * 3, axis=-1).copy()          # [F, H/2, W/2, 3] B,G,R
+        d_lo = torch.from_numpy(lo).cuda()
+        d_hi = torch.zeros((F, H, W, 3), dtype=torch.uint8, device="cuda")
 
     def step():
         if stripe:
@@ -142,6 +148,9 @@ def main():
             else:                                               # RCCL send/recv over xGMI
                 ext, s0 = sharding.exchange_halo(d_in[0], H, world, rank)
             ctx.forward_y_rows_dev(ext.data_ptr(), ext.stride(0), s0, d_out.data_ptr(), W, r0, W, H, r0, r1)
+        elif args.path == "pipeline":
+            for k in range(F):
+                ctx.process_bgr_dev(d_lo[k].data_ptr(), 3 * (W // 2), W // 2, H // 2, 2.0, d_hi[k].data_ptr(), 3 * W)
         elif args.path == "host":
             for k in range(F):
                 ctx.forward_y(frames[k], dst=host_out)

@@ -45,6 +45,7 @@ struct srcnn_ctx {
     DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
     // pipeline steps around the conv path
     DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
+    int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
 };
 
 namespace {
@@ -243,15 +244,19 @@ int resize_planes_dev(srcnn_ctx *c, const uint8_t *src, long sstride, long spitc
 {
     const size_t ints = (size_t)dw + dh, shorts = 4 * ((size_t)dw + dh);
     const size_t bytes = ints * 4 + shorts * 2;
-    std::vector<unsigned char> host(bytes);
-    int *xofs = reinterpret_cast<int *>(host.data()), *yofs = xofs + dw;
-    short *alpha = reinterpret_cast<short *>(yofs + dh), *beta = alpha + 4 * (size_t)dw;
-    cubic_table(sw, dw, xofs, alpha);
-    cubic_table(sh, dh, yofs, beta);
-    int rc;
-    if ((rc = reserve(c, c->tables, bytes))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));          // the previous launch may still read the tables
-    HIP_TRY(c, hipMemcpy(c->tables.p, host.data(), bytes, hipMemcpyHostToDevice));
+    if (!(c->tables.p && c->tab_sw == sw && c->tab_sh == sh && c->tab_dw == dw && c->tab_dh == dh)) {
+        // a stream of equally sized frames builds and uploads the tables once
+        std::vector<unsigned char> host(bytes);
+        int *xofs = reinterpret_cast<int *>(host.data()), *yofs = xofs + dw;
+        short *alpha = reinterpret_cast<short *>(yofs + dh), *beta = alpha + 4 * (size_t)dw;
+        cubic_table(sw, dw, xofs, alpha);
+        cubic_table(sh, dh, yofs, beta);
+        int rc;
+        if ((rc = reserve(c, c->tables, bytes))) return rc;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // an earlier launch may still read the old tables
+        HIP_TRY(c, hipMemcpy(c->tables.p, host.data(), bytes, hipMemcpyHostToDevice));
+        c->tab_sw = sw; c->tab_sh = sh; c->tab_dw = dw; c->tab_dh = dh;
+    }
     const int *dx = static_cast<const int *>(c->tables.p), *dy = dx + dw;
     const short *da = reinterpret_cast<const short *>(dy + dh), *db = da + 4 * (size_t)dw;
     HIP_TRY(c, launch_resize_cubic(src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, n_planes, dx, da, dy,
