@@ -1,0 +1,184 @@
+// srcnn_cli.cpp -- command-line front end with the reference tool's interface
+// (reference: parseArgs / printTitle / printHelp /
+// pthreadcall / main, src/srcnn.cpp:331-731), running the pipeline on the GPU.
+//
+//   srcnn_amd [--scale=F] [--noverbose] [--help] [--weights=FILE] source [output]
+//
+// Same argument rules as the reference: --scale= must be > 0 (default 2.0,
+// src/srcnn.cpp:40,359-370); first free argument = source, second = output;
+// default output "<name>_resized<ext>" (:396-416); without a source the title
+// and help are printed and the exit code is 0 (:709-715).  Exit codes: -1 image
+// load failure or scale too small (:479,:493), -10 no output (:684), 0 success.
+// The timed region ("Performace : N ms took.", :505,:659,:690) covers colour
+// conversion, resize, the conv path and the conversion back, as in the reference
+// -- here including the PCIe transfers -- and excludes file decode/encode.
+// Differences: image codecs are own PNG/PPM code (tools/image_io.hpp), not
+// OpenCV's, so JPEG etc. are not read; the model is loaded from a weight file
+// (--weights=, $SRCNN_WEIGHTS, or srcnn_cpp_amd/data next to the binary) instead
+// of being compiled in from convdata.h.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "image_io.hpp"
+#include "srcnn_amd.h"
+
+namespace {
+
+struct Options {
+    float scale = 2.0f;
+    bool verbose = true, help = false, copy = false;
+    std::string me, src, dst, weights;
+};
+
+bool starts_with(const std::string &s, const char *p) { return s.rfind(p, 0) == 0; }
+
+bool parse(int argc, char **argv, Options &o)
+{
+    for (int i = 0; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (i == 0) {
+            const size_t cut = a.find_last_of("/\\");
+            o.me = cut == std::string::npos ? a : a.substr(cut + 1);
+        } else if (starts_with(a, "--scale=")) {
+            const float v = (float)std::atof(a.c_str() + 8);
+            if (v > 0.f) o.scale = v;
+        } else if (starts_with(a, "--noverbose")) {
+            o.verbose = false;
+        } else if (starts_with(a, "--help")) {
+            o.help = true;
+        } else if (a == "--copy") {          // codec self-test: decode source, encode output, no GPU
+            o.copy = true;
+        } else if (starts_with(a, "--weights=")) {
+            o.weights = a.substr(10);
+        } else if (o.src.empty()) {
+            o.src = a;
+        } else if (o.dst.empty()) {
+            o.dst = a;
+        }
+    }
+    if (o.help || o.src.empty()) return false;
+    if (o.dst.empty()) {
+        const size_t dot = o.src.find_last_of('.');
+        o.dst = dot == std::string::npos ? o.src + "_resized"
+                                         : o.src.substr(0, dot) + "_resized" + o.src.substr(dot);
+    }
+    return true;
+}
+
+void title(const Options &o)
+{
+    std::printf("%s : Super-Resolution with deep Convolutional Neural Networks\n", o.me.c_str());
+    std::printf("MI355X (gfx950) HIP path, C ABI version %d; interface of SRCNN_Cpp's srcnn tool\n",
+                srcnn_abi_version());
+}
+
+void help(const Options &o)
+{
+    std::printf("\n    usage : %s (options) [source file name] ([output file name])\n\n", o.me.c_str());
+    std::printf("    _options_:\n\n");
+    std::printf("        --scale=( ratio: 0.1 to .. ) : scaling by ratio.\n");
+    std::printf("        --noverbose                  : turns off all verbose\n");
+    std::printf("        --weights=FILE               : 8129-float model blob (convdata.h order)\n");
+    std::printf("        --help                       : this help\n\n");
+}
+
+bool load_weights(const Options &o, const char *argv0, std::vector<float> &blob)
+{
+    std::vector<std::string> cand;
+    if (!o.weights.empty()) cand.push_back(o.weights);
+    if (const char *e = std::getenv("SRCNN_WEIGHTS")) cand.push_back(e);
+    std::string dir = argv0;
+    const size_t cut = dir.find_last_of('/');
+    dir = cut == std::string::npos ? "." : dir.substr(0, cut);
+    cand.push_back(dir + "/../srcnn_cpp_amd/data/srcnn915_weights.f32");
+    cand.push_back(dir + "/srcnn915_weights.f32");
+    cand.push_back("srcnn_cpp_amd/data/srcnn915_weights.f32");
+    for (const auto &p : cand) {
+        FILE *f = std::fopen(p.c_str(), "rb");
+        if (!f) continue;
+        blob.resize(8129);
+        const bool ok = std::fread(blob.data(), 4, 8129, f) == 8129;
+        std::fclose(f);
+        if (ok) return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Options o;
+    if (!parse(argc, argv, o)) {
+        title(o);
+        help(o);
+        std::fflush(stdout);
+        return 0;
+    }
+    if (o.verbose) {
+        title(o);
+        std::printf("\n- Scale multiply ratio : %.2f\n", o.scale);
+    }
+    imgio::Image in = imgio::imread(o.src);
+    if (in.empty()) {
+        if (o.verbose) std::printf("- load failure : %s\n", o.src.c_str());
+        return -1;
+    }
+    if (o.verbose) std::printf("- Image load : %s\n", o.src.c_str());
+    if (o.copy) return imgio::imwrite(o.dst, in.bgr.data(), in.width, in.height) ? 0 : -10;
+    int ow = 0, oh = 0;
+    if (srcnn_scaled_size(in.width, in.height, o.scale, &ow, &oh) != SRCNN_OK) {
+        if (o.verbose) std::printf("- Image scale error : ratio too small.\n");
+        return -1;
+    }
+    std::vector<float> w;
+    if (!load_weights(o, argv[0], w)) {
+        std::printf("- model load failure (use --weights=FILE or $SRCNN_WEIGHTS)\n");
+        return -1;
+    }
+    srcnn_ctx *ctx = nullptr;
+    int rc = srcnn_create(&ctx, 0);
+    if (rc != SRCNN_OK) {
+        std::printf("- GPU failure : no usable gfx950 device (error %d); there is no CPU fallback\n", rc);
+        return -1;
+    }
+    const float *b1 = w.data(), *w1 = b1 + 64, *b2 = w1 + 5184, *w2 = b2 + 32, *w3 = w2 + 2048 + 1;
+    rc = srcnn_set_weights(ctx, w1, b1, w2, b2, w3, w[7328]);
+    std::vector<unsigned char> out((size_t)ow * oh * 3);
+    if (rc == SRCNN_OK) {   // warm the context up outside the timed region (module load, buffer allocation)
+        std::vector<unsigned char> tin(3 * 16 * 16, 128), tout((size_t)3 * (int)(16 * o.scale) * (int)(16 * o.scale) + 3);
+        int tw, th;
+        if (srcnn_scaled_size(16, 16, o.scale, &tw, &th) == SRCNN_OK)
+            (void)srcnn_process_bgr(ctx, tin.data(), 48, 16, 16, o.scale, tout.data(), 3 * (size_t)tw);
+    }
+    if (o.verbose) {
+        std::printf("- Image converting to Y-Cr-Cb, resizing with bicubic interpolation,\n");
+        std::printf("  convolutional layers I + II + III, converting to BGR (one GPU pipeline) : ");
+        std::fflush(stdout);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rc == SRCNN_OK)
+        rc = srcnn_process_bgr(ctx, in.bgr.data(), 3 * (size_t)in.width, in.width, in.height, o.scale, out.data(),
+                               3 * (size_t)ow);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc != SRCNN_OK) {
+        if (o.verbose) std::printf("Failure.\n- %s\n", srcnn_last_error(ctx));
+        srcnn_destroy(ctx);
+        return -10;
+    }
+    if (o.verbose) {
+        std::printf("Ok.\n- Writing result to %s : ", o.dst.c_str());
+        std::fflush(stdout);
+    }
+    const bool wrote = imgio::imwrite(o.dst, out.data(), ow, oh);
+    if (o.verbose) std::printf(wrote ? "Ok.\n" : "Failure.\n");
+    if (o.verbose)
+        std::printf("- Performace : %u ms took.\n",
+                    (unsigned)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+    std::fflush(stdout);
+    srcnn_destroy(ctx);
+    return wrote ? 0 : -10;
+}
