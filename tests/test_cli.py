@@ -18,7 +18,7 @@ def cli(tmp_path_factory):
     B.build()
     exe = tmp_path_factory.mktemp("cli") / "srcnn_amd"
     subprocess.run(["g++", "-std=c++17", "-O2", f"-I{ROOT / 'include'}", f"-I{ROOT / 'tools'}",
-                    str(ROOT / "tools" / "srcnn_cli.cpp"), f"-L{ROOT / 'srcnn_cpp_amd'}", "-lsrcnn_amd", "-lz",
+                    str(ROOT / "tools" / "srcnn_cli.cpp"), f"-L{ROOT / 'srcnn_cpp_amd'}", "-lsrcnn_amd", "-lz", "-ldl",
                     f"-Wl,-rpath,{ROOT / 'srcnn_cpp_amd'}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     return exe
 

@@ -14,8 +14,10 @@
 // -- here including the PCIe transfers -- and excludes file decode/encode.
 // Differences: image codecs are own PNG/PPM code (tools/image_io.hpp), not
 // OpenCV's, so JPEG etc. are not read; the model is loaded from a weight file
-// (--weights=, $SRCNN_WEIGHTS, or srcnn_cpp_amd/data next to the binary) instead
+// (--weights=, $SRCNN_WEIGHTS, or data/ next to libsrcnn_amd.so) instead
 // of being compiled in from convdata.h.
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -93,6 +95,12 @@ bool load_weights(const Options &o, const char *argv0, std::vector<float> &blob)
     std::string dir = argv0;
     const size_t cut = dir.find_last_of('/');
     dir = cut == std::string::npos ? "." : dir.substr(0, cut);
+    Dl_info info;                                  // the blob shipped next to libsrcnn_amd.so
+    if (dladdr(reinterpret_cast<void *>(&srcnn_create), &info) && info.dli_fname) {
+        std::string lib = info.dli_fname;
+        const size_t lc = lib.find_last_of('/');
+        cand.push_back((lc == std::string::npos ? std::string(".") : lib.substr(0, lc)) + "/data/srcnn915_weights.f32");
+    }
     cand.push_back(dir + "/../srcnn_cpp_amd/data/srcnn915_weights.f32");
     cand.push_back(dir + "/srcnn915_weights.f32");
     cand.push_back("srcnn_cpp_amd/data/srcnn915_weights.f32");
