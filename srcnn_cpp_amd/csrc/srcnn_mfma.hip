@@ -82,7 +82,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     constexpr int OWM = FW - 2 * HALO;                 // output columns per strip
 
     const int W = p.width, H = p.height;
+    // XCD-aware work mapping: workgroups with equal blockIdx % 8 share an XCD (and its L2), so hand
+    // each XCD a CONTIGUOUS range of work items -- neighbouring strips / segments, which share their
+    // 12 halo columns / rows of Y -- instead of every 8th one.  Bijective for any grid size; speed
+    // only (the input is 1 B/pixel, so the effect on this MFMA-bound kernel is within noise).
     int bid = blockIdx.x;
+    if (!(p.tune & 8)) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
     const int strip = bid % p.n_strips;
     bid /= p.n_strips;
     const int seg = bid % p.n_segs;
