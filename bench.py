@@ -133,6 +133,7 @@ def main():
     d_work = torch.empty((F, 32, H, W), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
 
     host_out = np.empty_like(frames[0])
+    host_frames = np.empty_like(frames) if args.path == "host" and F > 1 else None
     if args.path == "pipeline":
         if W % 2 or H % 2 or stripe:
             raise SystemExit("--path pipeline upsamples x2: width and height must be even")
@@ -152,8 +153,10 @@ def main():
             for k in range(F):
                 ctx.process_bgr_dev(d_lo[k].data_ptr(), 3 * (W // 2), W // 2, H // 2, 2.0, d_hi[k].data_ptr(), 3 * W)
         elif args.path == "host":
-            for k in range(F):
-                ctx.forward_y(frames[k], dst=host_out)
+            if F == 1:
+                ctx.forward_y(frames[0], dst=host_out)
+            else:                                             # stream of host frames, transfers overlapped
+                ctx.forward_y_frames(frames, out=host_frames)
         elif args.path == "fused":
             ctx.forward_y_dev(d_in.data_ptr(), W, H * W, d_out.data_ptr(), W, H * W, W, H, F)
         else:

@@ -120,6 +120,13 @@ int srcnn_forward_y(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
                     uint8_t *dst, size_t dst_stride, int width, int height,
                     float *preclamp, size_t preclamp_stride);
 
+/* A stream of n_frames equally sized host frames (BASELINE configs[4]): uploads,
+ * kernels and downloads of neighbouring frames overlap on two internal HIP
+ * streams, so the PCIe transfers hide behind the kernel.  Returns when every
+ * dst[i] is complete. */
+int srcnn_forward_y_frames(srcnn_ctx *ctx, const uint8_t *const *src, size_t src_stride,
+                           uint8_t *const *dst, size_t dst_stride, int width, int height, int n_frames);
+
 /* ---- device-resident entry points (pointers are DEVICE memory) ------------- *
  * Asynchronous on the context's stream; the caller synchronises.               */
 

@@ -93,6 +93,7 @@ def load_library() -> C.CDLL:
         "srcnn_conv99x11": ([vp, _u8p, sz, _f32pp, sz, i, i, _f32p, _f32p, _f32p, _f32p], i),
         "srcnn_set_weights": ([vp, _f32p, _f32p, _f32p, _f32p, _f32p, C.c_float], i),
         "srcnn_forward_y": ([vp, _u8p, sz, _u8p, sz, i, i, _f32p, sz], i),
+        "srcnn_forward_y_frames": ([vp, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
         "srcnn_forward_y_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
         "srcnn_forward_y_rows_dev": ([vp, vp, sz, i, vp, sz, i, i, i, i, i], i),
         "srcnn_forward_y_unfused_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
@@ -117,7 +118,8 @@ def load_library() -> C.CDLL:
 ABI_SYMBOLS = (
     "srcnn_abi_version", "srcnn_create", "srcnn_destroy", "srcnn_last_error", "srcnn_set_mode",
     "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_conv99", "srcnn_conv11",
-    "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_dev",
+    "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_frames",
+    "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
@@ -278,6 +280,17 @@ class Context:
         self._check(self._lib.srcnn_forward_y(self._h, src.ctypes.data_as(_u8p), ss,
                                               dst.ctypes.data_as(_u8p), ds, w, h, pp, ps))
         return dst
+
+    def forward_y_frames(self, frames, out=None):
+        """A stream of equally sized host frames ([n,h,w] uint8), PCIe transfers overlapped with compute."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, h, w = frames.shape
+        if out is None:
+            out = np.empty_like(frames)
+        srcs = (_u8p * n)(*[frames[k].ctypes.data_as(_u8p) for k in range(n)])
+        dsts = (_u8p * n)(*[out[k].ctypes.data_as(_u8p) for k in range(n)])
+        self._check(self._lib.srcnn_forward_y_frames(self._h, srcs, w, dsts, w, w, h, n))
+        return out
 
     # -- device-resident entry points (integer device addresses) -------------
     def forward_y_dev(self, d_src, src_stride, src_frame_pitch, d_dst, dst_stride, dst_frame_pitch,

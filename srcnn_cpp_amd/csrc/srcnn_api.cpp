@@ -46,6 +46,11 @@ struct srcnn_ctx {
     // pipeline steps around the conv path
     DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
     int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
+    // second lane of the host-frame pipeline (srcnn_forward_y_frames)
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    DevBuf lane_in[2], lane_out[2];
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
+    size_t pin_cap = 0;
 };
 
 namespace {
@@ -322,6 +327,13 @@ void srcnn_destroy(srcnn_ctx *c)
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
                       &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables})
         release(*b);
+    for (int k = 0; k < 2; ++k) {
+        release(c->lane_in[k]);
+        release(c->lane_out[k]);
+        if (c->pin_in[k]) (void)hipHostFree(c->pin_in[k]);
+        if (c->pin_out[k]) (void)hipHostFree(c->pin_out[k]);
+        if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -558,6 +570,82 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
 }
 
 /* ------------------------- host-buffer entry points ------------------------- */
+
+/* A stream of host frames (BASELINE configs[4] shape): two lanes, each with its own HIP stream and
+ * device buffers, alternate, so frame i+1's upload and frame i-1's download run while frame i's
+ * kernel computes -- the PCIe transfers hide behind the MFMA-bound kernel. */
+int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_stride, uint8_t *const *dst,
+                           size_t dst_stride, int width, int height, int n_frames)
+{
+    int rc = bind(c);
+    if (rc) return rc;
+    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!src || !dst || n_frames <= 0 || width <= 0 || height <= 0 || src_stride < (size_t)width ||
+        dst_stride < (size_t)width)
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_frames: bad arguments");
+    for (int i = 0; i < n_frames; ++i)
+        if (!src[i] || !dst[i]) return fail(c, SRCNN_ERR_INVALID, "forward_y_frames: null frame %d", i);
+    if (c->mode == SRCNN_MODE_EXACT) {          // verification mode: no pipelining
+        for (int i = 0; i < n_frames; ++i)
+            if ((rc = srcnn_forward_y(c, src[i], src_stride, dst[i], dst_stride, width, height, nullptr, 0)))
+                return rc;
+        return SRCNN_OK;
+    }
+    const size_t n = (size_t)width * height;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {
+        if (!c->lane_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+        if ((rc = reserve(c, c->lane_in[k], n))) return rc;
+        if ((rc = reserve(c, c->lane_out[k], n))) return rc;
+    }
+    if (c->pin_cap < n) {       // pinned staging: copies from/to pageable memory would serialise the lanes
+        for (int k = 0; k < 2; ++k) {
+            if (c->pin_in[k]) (void)hipHostFree(c->pin_in[k]);
+            if (c->pin_out[k]) (void)hipHostFree(c->pin_out[k]);
+            c->pin_in[k] = c->pin_out[k] = nullptr;
+        }
+        c->pin_cap = 0;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(c, hipHostMalloc(&c->pin_in[k], n, hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc(&c->pin_out[k], n, hipHostMallocDefault));
+        }
+        c->pin_cap = n;
+    }
+    hipStream_t caller = c->stream;
+    auto rows_copy = [&](uint8_t *d, size_t ds, const uint8_t *sp, size_t ss) {
+        if (ds == (size_t)width && ss == (size_t)width) std::memcpy(d, sp, n);
+        else for (int r = 0; r < height; ++r) std::memcpy(d + (size_t)r * ds, sp + (size_t)r * ss, (size_t)width);
+    };
+    auto finish = [&](int i) -> hipError_t {           // wait for frame i's lane, hand the plane to the caller
+        const int k = i & 1;
+        hipError_t e = hipStreamSynchronize(c->lane_stream[k]);
+        if (e == hipSuccess) rows_copy(dst[i], dst_stride, static_cast<const uint8_t *>(c->pin_out[k]), width);
+        return e;
+    };
+    for (int i = 0; i < n_frames && rc == SRCNN_OK; ++i) {
+        const int k = i & 1;
+        // lane k is idle here: frame i-2 was finished in the previous iteration
+        rows_copy(static_cast<uint8_t *>(c->pin_in[k]), width, src[i], src_stride);     // overlaps kernel i-1
+        hipError_t e = hipMemcpyAsync(c->lane_in[k].p, c->pin_in[k], n, hipMemcpyHostToDevice, c->lane_stream[k]);
+        if (e == hipSuccess) {
+            c->stream = c->lane_stream[k];
+            rc = srcnn_forward_y_dev(c, static_cast<uint8_t *>(c->lane_in[k].p), width, n,
+                                     static_cast<uint8_t *>(c->lane_out[k].p), width, n, width, height, 1, nullptr);
+            c->stream = caller;
+        }
+        if (e == hipSuccess && rc == SRCNN_OK)
+            e = hipMemcpyAsync(c->pin_out[k], c->lane_out[k].p, n, hipMemcpyDeviceToHost, c->lane_stream[k]);
+        if (e == hipSuccess && rc == SRCNN_OK && i > 0) e = finish(i - 1);                // overlaps kernel i
+        if (e != hipSuccess && rc == SRCNN_OK)
+            rc = fail(c, SRCNN_ERR_HIP, "forward_y_frames: %s", hipGetErrorString(e));
+    }
+    if (rc == SRCNN_OK) {
+        hipError_t e = finish(n_frames - 1);
+        if (e != hipSuccess) rc = fail(c, SRCNN_ERR_HIP, "forward_y_frames: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(c->lane_stream[k]);
+    return rc;
+}
 
 int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t *dst, size_t dst_stride,
                     int width, int height, float *preclamp, size_t preclamp_stride)

@@ -351,3 +351,16 @@ def test_fused_kernel_is_deterministic_under_load(gpu_ctx, weights_blob):
         if w * h < 500000:
             m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
             assert np.array_equal(first, m_out)
+
+
+def test_host_frame_stream(gpu_ctx, weights_blob):
+    """configs[4] shape in miniature through srcnn_forward_y_frames: a stream of host frames
+    with overlapped transfers gives the same bytes as frame-by-frame calls."""
+    frames = synth_batch(300, 77, 7, first_frame=20)
+    out = gpu_ctx.forward_y_frames(frames)
+    for k in range(7):
+        assert np.array_equal(out[k], gpu_ctx.forward_y(frames[k]))
+    m_out, _ = oracle.gpuorder_forward_y(frames[3], weights_blob)
+    assert np.array_equal(out[3], m_out)
+    one = gpu_ctx.forward_y_frames(frames[:1])
+    assert np.array_equal(one[0], out[0])

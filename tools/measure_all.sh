@@ -11,6 +11,7 @@ run --steps 3 --frames 64 --path unfused                        # configs[2], ma
 run --steps 20 --width 7680 --height 4320                       # configs[3] plane on one GPU
 run --steps 5 --width 5760 --height 3240 --frames 8             # configs[4] frames (8 of the 512) on one GPU
 run --steps 20 --width 576 --height 576                         # configs[0] plane on the GPU
+run --steps 5 --path host --frames 32                           # stream of host frames, transfers overlapped
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode
