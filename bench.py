@@ -198,13 +198,17 @@ def main():
         value = pix_per_step * args.steps / elapsed / 1e6
         flops_per_launch = S.FLOP_PER_PIXEL * W * (r1 - r0 if stripe else H * F)
         achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch and MFMA-pipe utilisation come from rocprofv3 PMC passes of this same
+        # command (separate --pmc runs, profiles/r01/README.md); they cannot be read live.
+        traffic = mfma_busy = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
+        if pmc.exists() and args.mode == "mfma" and not stripe:
             try:
-                traffic = json.loads(pmc.read_text()).get(f"{args.path}_{W}x{H}x{F}")
+                rec = json.loads(pmc.read_text())
+                traffic = rec.get(f"{args.path}_{W}x{H}x{F}")
+                mfma_busy = rec.get(f"{args.path}_{W}x{H}x{F}_mfma_busy_frac")
             except Exception:
-                traffic = None
+                traffic = mfma_busy = None
         out = {
             "metric": "SRCNN Y-channel Mpixels/sec", "value": round(value, 2), "unit": "MPix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,7 +224,9 @@ def main():
                        "plan": ctx.query_plan(W, r1 - r0 if stripe else H, F), "output_checksum": chk},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic, "kernel_ms": round(kern_ms, 4),
+                         "traffic": traffic,
+                         "hbm_gbps": round(traffic / (kern_ms * 1e-3) / 1e9, 1) if traffic else None,
+                         "mfma_busy_frac_pmc": mfma_busy, "kernel_ms": round(kern_ms, 4),
                          "flop_per_pixel": S.FLOP_PER_PIXEL},
         }
         if world == 1 and not args.no_cpu_baseline:
