@@ -364,3 +364,34 @@ def test_host_frame_stream(gpu_ctx, weights_blob):
     assert np.array_equal(out[3], m_out)
     one = gpu_ctx.forward_y_frames(frames[:1])
     assert np.array_equal(one[0], out[0])
+
+
+def test_random_shapes_and_strides(gpu_ctx, weights_blob):
+    """Randomised sweep: plane sizes 1..400 (biased to strip / unit boundaries), padded row
+    strides on both sides, all three MFMA entry points -- every result bitwise equal to the
+    FMA-order model and within tolerance of the reference arithmetic."""
+    rng = np.random.default_rng(20261002)
+    w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
+    special = [1, 2, 3, 4, 5, 8, 9, 31, 32, 33, 63, 64, 65, 123, 124, 125, 127, 128, 129, 247, 248, 249, 372]
+    for it in range(28):
+        w = int(rng.choice(special)) if rng.random() < 0.6 else int(rng.integers(1, 400))
+        h = int(rng.choice(special[:17])) if rng.random() < 0.5 else int(rng.integers(1, 120))
+        pad_in, pad_out = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+        ybuf = np.zeros((h, w + pad_in), np.uint8)
+        ybuf[:, :w] = synth_luma(w, h, frame=it) if it % 4 else rng.integers(0, 256, (h, w), dtype=np.uint8)
+        y = ybuf[:, :w]
+        yc = np.ascontiguousarray(y)
+        obuf = np.full((h, w + pad_out), 3, np.uint8)
+        gpu_ctx.forward_y(y, dst=obuf[:, :w])
+        m_out, _ = oracle.gpuorder_forward_y(yc, weights_blob)
+        r_out, r_pre = oracle.forward_y(yc, weights_blob)
+        assert np.array_equal(obuf[:, :w], m_out), (w, h, pad_in, pad_out)
+        assert (obuf[:, w:] == 3).all()
+        check_u8(obuf[:, :w], r_out, r_pre)
+        if it % 3 == 0:      # the two-kernel surface on the same plane
+            buf, dst = planes32(h, w, stride=w + pad_out)
+            gpu_ctx.conv99x11(y, dst, w1, b1, w2, b2)
+            assert np.array_equal(buf[:, :, :w], oracle.gpuorder_conv99x11(yc, w1, b1, w2, b2)), (w, h)
+            o2 = np.empty((h, w), np.uint8)
+            gpu_ctx.conv55([buf[k, :, :w] for k in range(32)], o2, w3, b3)
+            assert np.array_equal(o2, m_out), (w, h)
