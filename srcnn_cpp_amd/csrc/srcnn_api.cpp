@@ -205,6 +205,24 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.seg_rows = pl.seg_rows;
     p.n_strips = pl.n_strips;
     p.n_segs = pl.n_segs;
+    p.n_tall = 0;
+    p.tall_rows = 0;
+    // Skewed split (see srcnn_mfma.hip): one frame, one round, two workgroups on (almost) every CU.
+    // 10 % measured best on MI355X (profiles/r01/skew_sweep.txt); SRCNN_DEBUG_SKEW=0 turns it off.
+    static const char *env_skew = std::getenv("SRCNN_DEBUG_SKEW");
+    const int skew_pct = env_skew ? std::atoi(env_skew) : 10;
+    const long wgs = (long)pl.n_strips * pl.n_segs;
+    if (skew_pct > 0 && mode != MODE_L12 && n_frames == 1 && pl.n_segs >= 2 && pl.n_segs % 2 == 0 &&
+        wgs <= 2L * c->n_cu && wgs > c->n_cu && (long)pl.n_strips * (pl.n_segs / 2) <= c->n_cu) {
+        const int rows = p.row_end - p.row_begin, nt = pl.n_segs / 2;
+        const int tall = pl.seg_rows + (pl.seg_rows * skew_pct + 50) / 100;
+        const int rest = rows - nt * tall;
+        if (rest >= nt) {
+            p.n_tall = nt;
+            p.tall_rows = tall;
+            p.seg_rows = (rest + nt - 1) / nt;          // short segments cover the remainder
+        }
+    }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
     p.sink = static_cast<float *>(c->sink.p);
     p.b3 = c->b3;

@@ -87,19 +87,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     // 12 halo columns / rows of Y -- instead of every 8th one.  Bijective for any grid size; speed
     // only (the input is 1 B/pixel, so the effect on this MFMA-bound kernel is within noise).
     int bid = blockIdx.x;
-    if (!(p.tune & 8)) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int strip, seg, frame = 0;
+    if (p.n_tall > 0) {
+        // Skewed split for launches that fit the GPU in one round with two workgroups per CU: the
+        // hardware fills every CU's first wave slots with the first n_cu blocks and arbitrates the
+        // MFMA pipe by age, so the earlier-dispatched workgroup of a CU runs ~12 % faster than the
+        // later one.  Hand the TALL segments to the low block ids so both finish together
+        // (measured dispatch order, profiles/r01; speed only -- any placement computes the same plane).
+        const int n_tall_items = p.n_strips * p.n_tall;
+        const bool tall = bid < n_tall_items;
+        const int j = tall ? bid : bid - n_tall_items;
+        strip = j % p.n_strips;
+        seg = (tall ? 0 : p.n_tall) + j / p.n_strips;
+    } else {
+        if (!(p.tune & 8)) {
+            const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        }
+        strip = bid % p.n_strips;
+        bid /= p.n_strips;
+        seg = bid % p.n_segs;
+        frame = bid / p.n_segs;
     }
-    const int strip = bid % p.n_strips;
-    bid /= p.n_strips;
-    const int seg = bid % p.n_segs;
-    const int frame = bid / p.n_segs;
 
     const int xs = strip * OWM;        // first output column of the strip
     const int gx0 = xs - HALO;         // image column of feature column xi = 0
-    const int ys = p.row_begin + seg * p.seg_rows;
-    const int ye = min(ys + p.seg_rows, p.row_end);
+    int ys, ye;
+    if (p.n_tall > 0) {
+        const bool tall = seg < p.n_tall;
+        ys = p.row_begin + (tall ? seg * p.tall_rows : p.n_tall * p.tall_rows + (seg - p.n_tall) * p.seg_rows);
+        ye = min(ys + (tall ? p.tall_rows : p.seg_rows), p.row_end);
+    } else {
+        ys = p.row_begin + seg * p.seg_rows;
+        ye = min(ys + p.seg_rows, p.row_end);
+    }
     const int f_lo = max(ys - HALO, 0);
     const int f_hi = min(ye + HALO, H);   // feature rows [f_lo, f_hi) are computed
 

@@ -36,3 +36,10 @@ slot = (hwid.astype(np.int64) & 0xF)
 for sl in np.unique(slot):
     m = slot == sl
     print(f"  wave slot {sl}: {m.sum()} waves, total cycles median {np.median(tot[m]):.0f}, L1/row {np.median((l1/rows)[m]):.0f}, bar/row {np.median((bar/rows)[m]):.0f}")
+# dispatch-order check: do the first n_cu blocks (hardware order = blockIdx) take wave slot 0 of distinct CUs?
+blk = np.arange(n) // 4
+first = blk < 256
+print(f"blocks <256 in slot 0: {(slot[first] == 0).mean():.3f};  blocks >=256 in slot 1: {(slot[~first] == 1).mean():.3f}")
+cu = (hwid.astype(np.int64) >> 8) & 0xF
+se = (hwid.astype(np.int64) >> 13) & 0x7
+print("lifetime (cycles) by block range: <256:", np.median(tot[first]), " >=256:", np.median(tot[~first]))
