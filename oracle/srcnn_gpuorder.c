@@ -16,9 +16,10 @@
  *               "tap" (x = 1.0), i.e. fmaf(b, 1, t) == t + b rounded once.
  *   layer 3     the 5x5x32 contraction is split as  T[tap] = sum_c W3[c][tap]*F[c]
  *               (fmaf chain, channels ascending, float) per FEATURE pixel,
- *               followed by a float shifted sum of the 25 tap planes:
- *               c_m = (((T[5m]+T[5m+1])+T[5m+2])+T[5m+3])+T[5m+4] with the
- *               column shifts n-2, out = ((((c_0+c_1)+c_2)+c_3)+c_4) + b3.
+ *               followed by a float shifted sum of the 25 tap planes, tap
+ *               rows first: F_n = (((T[n]+T[5+n])+T[10+n])+T[15+n])+T[20+n]
+ *               over the feature rows y-2..y+2 at column x+n-2, then
+ *               out = ((((F_0+F_1)+F_2)+F_3)+F_4) + b3.
  *               (The reference sums 25 taps in double per channel and then
  *               the 32 channels in float.)
  */
@@ -78,16 +79,18 @@ int srcnn_gpuorder_conv55(const float *const *src, size_t sstride, uint8_t *dst,
 #pragma omp parallel for
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
+            /* F_n = vertical sum over the 5 tap rows (m ascending) at column clamp(x+n-2),
+             * then the 5-term horizontal sum (n ascending), then the bias */
             float acc = 0.f;
-            for (int m = 0; m < 5; m++) {
-                int fy = clampi(y + m - 2, 0, height - 1);
-                float cm = 0.f;
-                for (int n = 0; n < 5; n++) {
-                    int fx = clampi(x + n - 2, 0, width - 1);
+            for (int n = 0; n < 5; n++) {
+                int fx = clampi(x + n - 2, 0, width - 1);
+                float fn = 0.f;
+                for (int m = 0; m < 5; m++) {
+                    int fy = clampi(y + m - 2, 0, height - 1);
                     float v = T[(m * 5 + n) * plane + (size_t)fy * width + fx];
-                    cm = (n == 0) ? v : cm + v;
+                    fn = (m == 0) ? v : fn + v;
                 }
-                acc = (m == 0) ? cm : acc + cm;
+                acc = (n == 0) ? fn : acc + fn;
             }
             float v = acc + bias;
             if (preclamp) preclamp[(size_t)y * dstride + x] = v;

@@ -119,8 +119,10 @@ void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *
         for (int t = 0; t < 2; ++t)
             for (int r = 0; r < 16; ++r)
                 out[(NFRAG_L1 + t * 16 + r) * 64 + l] = w2[ch * 64 + 32 * t + 2 * r + kk];
-        for (int r = 0; r < 16; ++r)
-            out[(NFRAG_L1 + NFRAG_L2 + r) * 64 + l] = i < 25 ? w3[(2 * r + kk) * 25 + i] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int tap = l3_row_tap(i);
+            out[(NFRAG_L1 + NFRAG_L2 + r) * 64 + l] = tap >= 0 ? w3[(2 * r + kk) * 25 + tap] : 0.f;
+        }
         for (int r = 0; r < 16; ++r)
             out[(NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + r) * 64 + l] = b2[2 * r + kk];
     }

@@ -13,14 +13,13 @@ constexpr int YP = FW + 8;         // Y ring pitch: strip + 4-pixel layer-1 bord
 constexpr int YR = 16;             // Y ring rows (each stored twice, see kernel)
 constexpr int NWAVES = FW / 32;    // one 32-pixel unit per wave per feature row
 constexpr int NTHREADS = NWAVES * 64;
-constexpr int ACC_ROWS = 8;        // output-row accumulator ring
 
 enum StripMode { MODE_FUSED = 0, MODE_L12 = 1, MODE_L3 = 2 };
 
 // Packed MFMA A-operand fragments, [NFRAG][64 lanes] floats (see pack_fragments()).
 constexpr int NFRAG_L1 = 82;       // 2 channel tiles x 41 k-steps (81 taps + bias tap)
 constexpr int NFRAG_L2 = 32;       // 2 x 16 k-steps over the 64 layer-1 channels
-constexpr int NFRAG_L3 = 16;       // 16 k-steps over the 32 layer-2 channels, rows = 25 taps (+7 zero)
+constexpr int NFRAG_L3 = 16;       // 16 k-steps over the 32 layer-2 channels, rows = 25 taps (+7 zero), see l3_row_tap()
 constexpr int NFRAG_B2 = 16;       // layer-2 bias laid out like the accumulator
 constexpr int NFRAG = NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + NFRAG_B2;
 
@@ -30,6 +29,14 @@ constexpr int NFRAG = NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + NFRAG_B2;
 // order, the reference's summation order).
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __host__ __device__ constexpr int row_chan(int i) { return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1); }
+
+// Layer-3 tap held by accumulator ROW i: register r = (i&3)+4(i>>3) of lane-half h = (i>>2)&1 holds
+// tap (m, n) with r = 5s+m, n = s (half 0) or 3+s (half 1); -1 for the 7 unused rows.  Returns 5m+n.
+__host__ __device__ constexpr int l3_row_tap(int i)
+{
+    const int r = (i & 3) + 4 * (i >> 3), h = (i >> 2) & 1, s = r / 5, m = r % 5, n = h ? 3 + s : s;
+    return (r < 15 && n < 5) ? 5 * m + n : -1;
+}
 
 struct StripParams {
     // layer-1 input (MODE_FUSED, MODE_L12)

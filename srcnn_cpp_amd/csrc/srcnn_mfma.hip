@@ -32,17 +32,17 @@
 // T[tap] = sum_c W3[c][tap] * F[c]; the output pixel is then the shifted sum
 // out(y,x) = b3 + sum_{m,n} T[5m+n](y+m-2, x+n-2) with the reference's
 // replicate border applied to the feature coordinates (src/srcnn.cpp:196-210).
-// Each finished T row is scattered through a double-buffered LDS tile into a
-// ring of output-row accumulators (5 horizontal 5-tap sums per pixel), so only
-// 2 x 25 x FW floats of T ever exist per workgroup.
+// A wave owns the same pixel columns on every row, so the sum over the 5 tap
+// ROWS is kept as register chains (12 adds per feature row); only the 5
+// finished per-tap-column values of a pixel cross lanes, through a small
+// double-buffered LDS tile, for the 5-term horizontal sum.
 //
 // HBM traffic of MODE_FUSED is ~1.1 B read + 1 B written per pixel; the kernel
 // is bound by the f32 MFMA pipe (130 MFMA x 64 cycles per 32 pixels per SIMD).
 //
-// LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + T tiles 2x25x128 f32
-// (25 KiB) + accumulator ring 9x128 f32 (4.5 KiB) = 46.5 KiB -> two workgroups per
-// CU, i.e. two waves per SIMD, so one wave's layer seams / LDS phase are
-// covered by the other's MFMA stream.
+// LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + F tiles 2x3x6x128 f32
+// (18 KiB) = 35 KiB; 216+ VGPRs -> two workgroups per CU, i.e. two waves per
+// SIMD, so one wave's non-MFMA instructions are covered by the other's MFMAs.
 #include "srcnn_kernels.h"
 
 #include <type_traits>
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *ylds = reinterpret_cast<float *>(smem);   // [2*YR][YP]   (MODE_FUSED, MODE_L12)
-    float *tbuf = ylds + 2 * YR * YP;                // [2][25][FW]  (MODE_FUSED, MODE_L3)
-    float *accr = tbuf + 2 * 25 * FW;                // [ACC_ROWS + 1][FW], last row = write sink
+    float *fbuf = ylds + 2 * YR * YP;                // [2][3][6][FW]  (MODE_FUSED, MODE_L3)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -194,10 +193,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     if constexpr (MODE == MODE_L3)
         plf = p.planes_in + (long)frame * p.pl_frame_pitch + clampi(gx, 0, W - 1);
 
-    // ---- layer-3 scatter-accumulate ("phase B") ------------------------------
-    // out(y,x) += c_m(x) for every (y,m) with clamp(y+m-2) == g, m ascending,
-    // c_m(x) = sum_n T[5m+n](g, clamp(x+n-2)).  Lanes l and l+32 own the same
-    // pixel and do identical work (no divergence; duplicate stores are benign).
+    // ---- layer 3, after the MFMA: vertical sums in registers, horizontal sums through LDS -----
+    // out(y,x) = b3 + sum_n F_n(y, clamp(x+n-2)),   F_n(y,x') = sum_m T[5m+n](clamp(y+m-2), x').
+    // The host packs W3 so that accumulator register 5s+m of lane-half 0 holds tap (m, n=s) and of
+    // lane-half 1 tap (m, n=3+s)  (s = 0..2; slot 2 of half 1 is unused).  A wave owns the same 32
+    // pixel columns on every row, so the sum over m (one tap row per feature row, m ascending) is a
+    // register chain: R[k][s] = taps m=0..k of the output row that is k+1 rows behind completion.
+    // Only the 5 finished values F_n per pixel cross lanes, through a double-buffered LDS tile;
+    // that 5-term shifted sum of the previous row runs inside the layer-1 MFMA stream of this row.
     int xn[5] = {0, 0, 0, 0, 0};
     bool px_ok = false;
     if constexpr (MODE != MODE_L12) {
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
         px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
     }
+    float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto finalize = [&](int y, float acc, bool ok) {
         const float v = acc + p.b3;
         const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
@@ -217,72 +221,77 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             *dp = v;
         }
     };
-    // any T row, including the image's first/last row (which feed several
-    // output rows per m through the replicate border)
-    auto pb_generic = [&](int g) {
-        const float *tr = tbuf + (g & 1) * 25 * FW;
+    // F tile: [parity of the feature row that completed it][slot][plane n][FW]; slot 0 = output row
+    // g-2, slots 1,2 = rows g-1, g, which only the image's last feature row g = H-1 completes.
+    auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
+    // After the layer-3 MFMAs of feature row f: advance the chains, emit the finished F values.
+    auto vertical = [&](int f, const f32x16 &t) {
+        const int fplane = 3 * half * FW + xi;              // half 0 -> planes 0..2, half 1 -> planes 3..5
+        if (f > 0) {
+            float *fo = ftile(f, 0) + fplane;
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            float cm = tr[(5 * m) * FW + xn[0]];
+            for (int s = 0; s < 3; ++s) {
+                fo[s * FW] = R[3][s] + t[5 * s + 4];          // output row f-2: taps m=0..3 + m=4
+                R[3][s] = R[2][s] + t[5 * s + 3];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[1][s] = R[0][s] + t[5 * s + 1];
+                R[0][s] = t[5 * s];
+            }
+        } else {
+            // image top: rows -1, -2 replicate row 0 (src/srcnn.cpp:203), so output rows 0 and 1
+            // start with m = 0..2 resp. m = 0..1 all taken from feature row 0
 #pragma unroll
-            for (int n = 1; n < 5; ++n) cm += tr[(5 * m + n) * FW + xn[n]];
-            int y0 = (g == 0) ? 0 : g - m + 2;
-            int y1 = (g == H - 1) ? H - 1 : g - m + 2;
-            y0 = max(y0, ys);
-            y1 = min(y1, ye - 1);
-            for (int y = y0; y <= y1; ++y) {
-                float *ap = accr + (y & (ACC_ROWS - 1)) * FW + xi;
-                const float acc = (m == 0) ? cm : *ap + cm;
-                if (m < 4) *ap = acc;
-                else finalize(y, acc, px_ok);
+            for (int s = 0; s < 3; ++s) {
+                R[0][s] = t[5 * s];
+                R[1][s] = t[5 * s] + t[5 * s + 1];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[3][s] = 0.f;
+            }
+        }
+        if (f == H - 1) {
+            // image bottom: rows H, H+1 replicate row H-1, which therefore also supplies
+            // m = 4 of output row H-2 and m = 3, 4 of output row H-1
+            float *f1 = ftile(f, 1) + fplane, *f2 = ftile(f, 2) + fplane;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                f1[s * FW] = R[3][s] + t[5 * s + 4];
+                f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
             }
         }
     };
-    // interior T row (0 < g < H-1): exactly one output row per m, y = g-m+2.
-    // Branch-free (rows outside the segment go to the sink row / scratch word)
-    // and split in a load half and a use half, so it can sit INSIDE the
-    // layer-1 MFMA stream with its LDS latency hidden.
-    float pbv[6];
-    auto pb_load = [&](int g, int m) {
-        const float *tr = tbuf + (g & 1) * 25 * FW;
+    // Horizontal 5-term sum of one finished output row, split in a load and a use half so it can sit
+    // inside the layer-1 MFMA stream with its LDS latency hidden.  Rows outside the segment and lanes
+    // without an output pixel store to the scratch word.
+    float hv[5];
+    auto hp_load = [&](int g, int slot) {
+        const float *fr = ftile(g, slot);
 #pragma unroll
-        for (int n = 0; n < 5; ++n) pbv[n] = tr[(5 * m + n) * FW + xn[n]];
-        if (m > 0) pbv[5] = accr[((g - m + 2) & (ACC_ROWS - 1)) * FW + xi];
+        for (int n = 0; n < 5; ++n) hv[n] = fr[n * FW + xn[n]];
     };
-    auto pb_use = [&](int g, int m) {
-        float cm = pbv[0];
+    auto hp_use = [&](int g, int slot) {
+        float acc = hv[0];
 #pragma unroll
-        for (int n = 1; n < 5; ++n) cm += pbv[n];
-        const int y = g - m + 2;
-        const bool row_ok = (y >= ys) && (y < ye);
-        const float acc = (m == 0) ? cm : pbv[5] + cm;
-        if (m < 4) accr[(row_ok ? (y & (ACC_ROWS - 1)) : ACC_ROWS) * FW + xi] = acc;
-        else finalize(y, acc, row_ok && px_ok);
+        for (int n = 1; n < 5; ++n) acc += hv[n];
+        const int y = g - 2 + slot;
+        finalize(y, acc, px_ok && (y >= ys) && (y < ye));
     };
 
-    // Row loop.  Iteration f computes T row f (layers 1-3, 130 MFMA per wave) and,
-    // INSIDE that MFMA stream, folds T row f-1 (finished at the previous
-    // barrier) into the output accumulators; one extra iteration drains the
-    // last row.  One barrier per row.
+    // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
+    // MFMA stream, finishes the output row that feature row f-1 completed; one extra iteration
+    // drains the last row(s).  One barrier per row.
     const int f_end = (MODE == MODE_L12) ? f_hi - 1 : f_hi;
     for (int f = f_lo; f <= f_end; ++f) {
         unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
         if constexpr (DIAG) dg_a = stamp();
         const bool do_a = f < f_hi;
         const int g = f - 1;
-        bool pb_fast = false;
-        if constexpr (MODE != MODE_L12) {
-            if (g >= f_lo) {
-                pb_fast = (g > 0) && (g < H - 1);
-                if (!pb_fast) pb_generic(g);
-            }
-        }
+        const bool hp = (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 whenever do_a
         if (!do_a) {
-            if (pb_fast) {
-#pragma unroll
-                for (int m = 0; m < 5; ++m) {
-                    pb_load(g, m);
-                    pb_use(g, m);
+            if (hp) {
+                const int nslots = (g == H - 1) ? 3 : 1;
+                for (int slot = 0; slot < nslots; ++slot) {
+                    hp_load(g, slot);
+                    hp_use(g, slot);
                 }
             }
             break;
@@ -317,8 +326,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                 for (int s = 0; s < 41; ++s) {
                     if (s + PF < 41) bq[s + PF] = ldb(s + PF);
                     if constexpr (PB && MODE != MODE_L12) {
-                        if (s % 8 == 1) pb_load(g, s / 8);
-                        if (s % 8 == 5) pb_use(g, s / 8);
+                        if (s == 2) hp_load(g, 0);
+                        if (s == 8) hp_use(g, 0);
                     }
                     a0 = MFMA(w1f[0][s], bq[s], a0);
                     a1 = MFMA(w1f[1][s], bq[s], a1);
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                 }
             };
             if constexpr (DIAG) dg_b = stamp();
-            if (pb_fast) layer1(std::true_type{});
+            if (hp) layer1(std::true_type{});
             else layer1(std::false_type{});
             if constexpr (DIAG) dg_c = stamp();
             // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
@@ -365,12 +374,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             const float *q = plf + (long)f * p.pl_stride;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[r] = q[(long)(2 * r + half) * p.pl_pitch];
-            if (pb_fast) {
-#pragma unroll
-                for (int m = 0; m < 5; ++m) {
-                    pb_load(g, m);
-                    pb_use(g, m);
-                }
+            if (hp) {
+                hp_load(g, 0);
+                hp_use(g, 0);
             }
         }
 
@@ -380,10 +386,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
             __builtin_amdgcn_sched_barrier(0);
-            float *tb = tbuf + (f & 1) * 25 * FW + xi;
-#pragma unroll
-            for (int r = 0; r < 12; ++r) tb[acc_row(r, 0) * FW + 4 * half * FW] = t[r];
-            if (half == 0) tb[24 * FW] = t[12];
+            vertical(f, t);
         }
 
         if constexpr (DIAG) dg_d = stamp();
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 
 size_t strip_lds_bytes(int /*mode*/)
 {
-    return sizeof(float) * (2 * YR * YP + 2 * 25 * FW + (ACC_ROWS + 1) * FW);
+    return sizeof(float) * (2 * YR * YP + 2 * 3 * 6 * FW);
 }
 
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
