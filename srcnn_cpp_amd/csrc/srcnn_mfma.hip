@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                     }
                     a0 = MFMA(w1f[0][s], bq[s], a0);
                     a1 = MFMA(w1f[1][s], bq[s], a1);
-                    // keep this k-step's LDS traffic / phase-B slice where it is
+                    // keep this k-step's LDS traffic / horizontal-sum slice where it is
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };

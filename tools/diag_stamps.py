@@ -29,8 +29,8 @@ clk = tot / real * 100e6
 print(f"waves {n}  rows/wave {rows.mean():.1f}")
 print(f"in-kernel clock GHz: median {np.median(clk)/1e9:.3f}  min {clk.min()/1e9:.3f} max {clk.max()/1e9:.3f}")
 print(f"kernel cycles per wave: median {np.median(tot):.0f}  max {tot.max():.0f}  -> per row {np.median(tot/rows):.0f}")
-for name, v in [("top(loop head->L1)", top), ("L1 (82 MFMA + phase B)", l1), ("L2+L3+T write", l23), ("barrier wait", bar)]:
-    print(f"  {name:26s} per row: median {np.median(v/rows):8.0f}   mean {np.mean(v/rows):8.0f}")
+for name, v in [("top(loop head->L1)", top), ("L1 (82 MFMA + horizontal sum of previous row)", l1), ("L2+L3+vertical chains+F write", l23), ("barrier wait", bar)]:
+    print(f"  {name:48s} per row: median {np.median(v/rows):8.0f}   mean {np.mean(v/rows):8.0f}")
 print("ideal MFMA cycles per row: L1 5248, L2+L3 3072, total 8320 (x2 waves per SIMD when 2 WG/CU)")
 slot = (hwid.astype(np.int64) & 0xF)
 for sl in np.unique(slot):
