@@ -55,6 +55,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// Row barrier.  The waves of a workgroup only exchange data through LDS, so the barrier has to
+// order LDS traffic only: __syncthreads() would also wait for every outstanding global store and
+// load (s_waitcnt vmcnt(0)) on every row, which stalls MODE_L12 behind its 16 plane stores per row.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ReLU as ONE v_max_f32 (fmaxf() adds a canonicalising v_max first).  For finite x,
 // max(x, 0) equals the reference's (x < 0) ? 0 : x  (src/srcnn.cpp:304,319) up to the sign of zero.
 __device__ __forceinline__ float relu(float x)
@@ -280,6 +288,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     // MFMA stream, finishes the output row that feature row f-1 completed; one extra iteration
     // drains the last row(s).  One barrier per row.
     const int f_end = (MODE == MODE_L12) ? f_hi - 1 : f_hi;
+    // MODE_L3 is bound by the 128 B/pixel it reads: the 16 plane loads of row f+1 are issued before
+    // row f is consumed, so a whole row of HBM latency hides behind the MFMAs and the row barrier.
+    f32x16 d2n = {0};
+    auto load_planes = [&](int f) {
+        const float *q = plf + (long)min(f, H - 1) * p.pl_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d2n[r] = q[(long)(2 * r + half) * p.pl_pitch];
+    };
+    if constexpr (MODE == MODE_L3) load_planes(f_lo);
     for (int f = f_lo; f <= f_end; ++f) {
         unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
         if constexpr (DIAG) dg_a = stamp();
@@ -371,9 +388,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                 }
             }
         } else {
-            const float *q = plf + (long)f * p.pl_stride;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d2[r] = q[(long)(2 * r + half) * p.pl_pitch];
+            d2 = d2n;
+            load_planes(f + 1);
             if (hp) {
                 hp_load(g, 0);
                 hp_use(g, 0);
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         }
 
         if constexpr (DIAG) dg_d = stamp();
-        __syncthreads();
+        lds_barrier();
         if constexpr (DIAG) {
             const unsigned long long e = stamp();
             dg_top += dg_b - dg_a;
