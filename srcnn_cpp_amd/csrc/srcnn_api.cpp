@@ -163,9 +163,10 @@ struct Plan {
     int seg_rows, n_strips, n_segs;
 };
 
-// Choose the row-segment height: taller segments waste fewer halo rows
-// (2*halo recomputed feature rows per segment), more segments fill the
-// 2-workgroups-per-CU slots more evenly.  Everything is regular, so scan.
+// Choose the row-segment height: taller segments waste fewer halo rows (2*halo recomputed feature
+// rows per segment) and fewer workgroup start-ups (weight fragments, 9-row Y prologue: worth about
+// STARTUP_ROWS rows), more segments fill the 2-workgroups-per-CU slots more evenly.  Everything is
+// regular, so scan.
 Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo)
 {
     const int ow = FW - 2 * halo;
@@ -180,7 +181,8 @@ Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo)
         const long wgs = (long)best.n_strips * ns * n_frames;
         const long rounds = (wgs + slots - 1) / slots;
         const double fill = (double)wgs / (double)(rounds * slots);
-        const double useful = (double)rows / ((double)ns * (seg + 2 * halo));
+        constexpr int STARTUP_ROWS = 3;
+        const double useful = (double)rows / ((double)ns * (seg + 2 * halo + STARTUP_ROWS));
         const double eff = fill * useful;
         if (eff > best_eff + 1e-9) {
             best_eff = eff;
