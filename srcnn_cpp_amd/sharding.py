@@ -117,7 +117,12 @@ def forward_striped(stripe, height: int, world: int, rank: int,
 
 
 def gpu_compute_rows(ctx) -> Callable:
-    """compute_rows for GPU tensors through the C ABI (srcnn_forward_y_rows_dev)."""
+    """compute_rows for GPU tensors through the C ABI (srcnn_forward_y_rows_dev).
+
+    The halo rows arrive on torch's current stream (``req.wait()`` of an NCCL/RCCL work
+    object orders that stream, not the host), so the context must launch on the same
+    stream: ``ctx.set_stream(torch.cuda.current_stream().cuda_stream)`` with a non-default
+    stream current, as ``bench.py`` does."""
     def run(ext, s0, out, dst_row0, height, r0, r1):
         if not ext.is_cuda:
             raise RuntimeError("the HIP path needs device tensors (no CPU fallback)")
