@@ -286,10 +286,18 @@ def test_full_size_4k_frame(gpu_ctx, weights_blob):
         ir0, ic0 = (0 if r0 == 0 else 6), (0 if c0 == 0 else 6)
         ir1, ic1 = (r1 - r0 if r1 == h else r1 - r0 - 6), (c1 - c0 if c1 == w else c1 - c0 - 6)
         assert np.array_equal(c_out[ir0:ir1, ic0:ic1], out[r0 + ir0:r0 + ir1, c0 + ic0:c0 + ic1])
+    # committed checksums of this frame, computed in the build container (tests/golden/make_4k_checksums.py)
+    import hashlib, json
+    from pathlib import Path
+    pins = json.loads((Path(__file__).resolve().parent / "golden" / "synthetic_4k_checksums.json").read_text())
+    assert hashlib.sha256(y.tobytes()).hexdigest() == pins["input_sha256"]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == pins["gpuorder_sha256"]
     m_out, m_pre = oracle.gpuorder_forward_y(y, weights_blob)
     assert np.array_equal(pre, m_pre)
     assert np.array_equal(out, m_out)
     r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert hashlib.sha256(r_out.tobytes()).hexdigest() == pins["oracle_sha256"]
+    assert int((out != r_out).sum()) == pins["u8_mismatches_between_them"]
     assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
     check_u8(out, r_out, r_pre)
 

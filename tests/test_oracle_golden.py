@@ -111,3 +111,13 @@ def test_oracle_regression_vectors(weights_blob):
         sums[(w, h, f)] = (int(out.astype(np.int64).sum()), hashlib.sha256(out.tobytes()).hexdigest()[:16])
     want = eval((GOLD / "oracle_selfpins.txt").read_text())
     assert sums == want
+
+
+def test_synthetic_generator_is_pinned():
+    """The integer-only generator must give identical bytes on every host (bench input, 4K pins)."""
+    import json
+    pins = json.loads((GOLD / "synthetic_4k_checksums.json").read_text())
+    assert hashlib.sha256(synth_luma(3840, 2160).tobytes()).hexdigest() == pins["input_sha256"]
+    a = synth_luma(64, 48, frame=3)
+    assert a.dtype == np.uint8 and a.max() <= 241 and np.array_equal(a, synth_luma(64, 48, frame=3))
+    assert not np.array_equal(a, synth_luma(64, 48, frame=4))
