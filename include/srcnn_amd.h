@@ -56,7 +56,7 @@ enum {
  *   SRCNN_MODE_EXACT reference arithmetic reproduced exactly on the vector
  *                    ALU (rounded multiply then rounded add, double 25-term
  *                    sums in layer 3): bit-identical to the reference CPU
- *                    path, roughly 11x slower (a verification mode). */
+ *                    path, roughly 3x slower (no FMA: two VALU operations per MAC). */
 enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1 };
 
 typedef struct srcnn_ctx srcnn_ctx;

@@ -140,13 +140,15 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     const float *w3 = k55 ? k55 : zero_w.data();
     std::vector<float> frag((size_t)NFRAG * 64);
     pack_fragments(w1, b1, w2, b2, w3, frag.data());
-    std::vector<float> raw(8129);
+    std::vector<float> raw(8129 + 2048);     // + W2 transposed [64][32] for the exact layer-1/2 kernel
     std::memcpy(raw.data(), b1, 64 * 4);
     std::memcpy(raw.data() + 64, w1, 5184 * 4);
     std::memcpy(raw.data() + 5248, b2, 32 * 4);
     std::memcpy(raw.data() + 5280, w2, 2048 * 4);
     raw[7328] = b55;
     std::memcpy(raw.data() + 7329, w3, 800 * 4);
+    for (int k = 0; k < 32; ++k)
+        for (int i = 0; i < 64; ++i) raw[8129 + i * 32 + k] = w2[k * 64 + i];
     int rc;
     if ((rc = reserve(c, c->wfrag, frag.size() * 4))) return rc;
     if ((rc = reserve(c, c->sink, 1 << 20))) return rc;   // scratch words (+ diagnostics in debug builds)

@@ -72,21 +72,25 @@ __global__ __launch_bounds__(256) void conv11_exact_kernel(const float *__restri
 }
 
 // ---- Convolution99x11, exact ---------------------------------------------
-// One pixel per lane; the weights are read through the scalar cache
-// (wave-uniform addresses), the 81 window pixels live in registers.
-// weights = b1[64] | W1[64][81] | b2[32] | W2[32][64]  (convdata.h order).
+// One pixel per lane, everything in registers: the 81 window pixels, and the 32
+// layer-2 accumulators.  Layer 2 sums its inputs in ascending channel order
+// (src/srcnn.cpp:312-315), so each layer-1 activation t_i is folded into the 32
+// running sums as soon as it exists -- same order, same roundings, no 64-float
+// scratch per pixel.  Weights are wave-uniform and come through the scalar
+// cache: weights = b1[64] | W1[64][81] | b2[32] | W2[32][64] (convdata.h order),
+// w2t = W2 transposed to [64][32] so that one channel's 32 weights are contiguous.
 __global__ __launch_bounds__(256) void conv99x11_exact_kernel(const uint8_t *__restrict__ src, long sstride,
                                                               long src_frame_pitch,
                                                               float *__restrict__ planes, long stride,
                                                               long pitch, long frame_pitch, int w, int h,
-                                                              const float *__restrict__ weights)
+                                                              const float *__restrict__ weights,
+                                                              const float *__restrict__ w2t)
 {
-    const float *b1 = weights, *w1 = weights + 64, *b2 = w1 + 64 * 81, *w2 = b2 + 32;
+    const float *b1 = weights, *w1 = weights + 64, *b2 = w1 + 64 * 81;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int frame = blockIdx.z;
     if (row >= h) return;
-    const bool ok = col < w;
     const uint8_t *sf = src + (long)frame * src_frame_pitch;
     float px[81];
 #pragma unroll
@@ -95,71 +99,92 @@ __global__ __launch_bounds__(256) void conv99x11_exact_kernel(const uint8_t *__r
 #pragma unroll
         for (int j = 0; j < 9; ++j) px[i * 9 + j] = (float)sr[clampi_e(col + j - 4, 0, w - 1)];
     }
-    // layer-1 activations of this pixel go through LDS (column tid) so the
-    // filter loop can stay rolled without dynamic register indexing.
-    __shared__ float tl[64][256];
-#pragma unroll 2
-    for (int k = 0; k < 64; ++k) {
+    float r[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r[k] = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+        const float *wi = w1 + i * 81;
         float a = 0.f;
 #pragma unroll
         for (int q = 0; q < 81; ++q) {
-            const float pr = w1[k * 81 + q] * px[q];
+            const float pr = wi[q] * px[q];
             a = a + pr;
         }
-        a = a + b1[k];
-        tl[k][threadIdx.x] = (a < 0) ? 0.f : a;
-    }
-    float *o = planes + (long)frame * frame_pitch + (long)row * stride + col;
-#pragma unroll 1
-    for (int k = 0; k < 32; ++k) {
-        float r = 0.f;
+        a = a + b1[i];
+        a = (a < 0) ? 0.f : a;
+        const float *w2i = w2t + i * 32;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float pr = tl[i][threadIdx.x] * w2[k * 64 + i];
-            r = r + pr;
+        for (int k = 0; k < 32; ++k) {
+            const float pr = a * w2i[k];
+            r[k] = r[k] + pr;
         }
-        r = r + b2[k];
-        r = (r < 0) ? 0.f : r;
-        if (ok) o[(long)k * pitch] = r;
+    }
+    if (col >= w) return;
+    float *o = planes + (long)frame * frame_pitch + (long)row * stride + col;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        float v = r[k] + b2[k];
+        v = (v < 0) ? 0.f : v;
+        o[(long)k * pitch] = v;
     }
 }
 
 // ---- Convolution55, exact ---------------------------------------------------
 // float product, double 25-term sum per channel, float running sum over the
-// channels (src/srcnn.cpp:218-240).
+// channels (src/srcnn.cpp:218-240).  A workgroup owns a 64x4 pixel tile; each
+// channel's 68x8 window (replicate border applied while loading) is staged in LDS,
+// double-buffered, so every plane element is fetched from HBM/L2 about once instead
+// of 25 times and the taps are LDS reads.
 __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restrict__ planes, long stride,
                                                            long pitch, long frame_pitch,
                                                            uint8_t *__restrict__ dst, float *__restrict__ pre,
                                                            long dstride, long dst_frame_pitch, int w, int h,
                                                            const float *__restrict__ kernel, float bias)
 {
+    constexpr int TW = 64, TH = 4, WW = TW + 4, WH = TH + 4, WN = WW * WH;   // 68 x 8 window
     __shared__ float kw[800];
+    __shared__ float win[2][WN];
     for (int q = threadIdx.x; q < 800; q += 256) kw[q] = kernel[q];
-    __syncthreads();
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * TW, row0 = blockIdx.y * TH;
+    const int col = col0 + tx, row = row0 + ty;
     const int frame = blockIdx.z;
-    if (col >= w || row >= h) return;
-    int rr[5], cc[5];
-#pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        rr[q] = clampi_e(row + q - 2, 0, h - 1);
-        cc[q] = clampi_e(col + q - 2, 0, w - 1);
-    }
     const float *pf = planes + (long)frame * frame_pitch;
+    // window elements this thread stages (WN = 544 = 2 x 256 + 32)
+    long off[3];
+    int idx[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        idx[q] = e < WN ? e : -1;
+        const int wy = e / WW, wx = e % WW;
+        off[q] = (long)clampi_e(row0 + wy - 2, 0, h - 1) * stride + clampi_e(col0 + wx - 2, 0, w - 1);
+    }
+    auto stage = [&](int ch, int buf) {
+        const float *pl = pf + (long)ch * pitch;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (idx[q] >= 0) win[buf][idx[q]] = pl[off[q]];
+    };
+    stage(0, 0);
+    __syncthreads();
     float temp = 0.f;
     for (int i = 0; i < 32; ++i) {
-        const float *pl = pf + (long)i * pitch;
+        if (i + 1 < 32) stage(i + 1, (i + 1) & 1);
+        const float *wv = &win[i & 1][ty * WW + tx];
         double tp = 0.0;
 #pragma unroll
         for (int m = 0; m < 5; ++m)
 #pragma unroll
             for (int n = 0; n < 5; ++n) {
-                const float pr = kw[(i * 5 + m) * 5 + n] * pl[(long)rr[m] * stride + cc[n]];
+                const float pr = kw[(i * 5 + m) * 5 + n] * wv[m * WW + n];
                 tp = tp + (double)pr;
             }
         temp = (float)((double)temp + tp);
+        __syncthreads();
     }
+    if (col >= w || row >= h) return;
     temp = temp + bias;
     const long o = (long)frame * dst_frame_pitch + (long)row * dstride + col;
     if (pre) pre[o] = temp;
@@ -190,8 +215,9 @@ hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_fra
                                   long stride, long pitch, long frame_pitch, int w, int h, int n_frames,
                                   const float *d_weights, hipStream_t st)
 {
+    // d_weights = convdata.h-order table (8,129 floats) followed by W2 transposed ([64][32])
     hipLaunchKernelGGL(conv99x11_exact_kernel, px_grid(w, h, n_frames), dim3(256), 0, st, src, sstride,
-                       src_frame_pitch, planes, stride, pitch, frame_pitch, w, h, d_weights);
+                       src_frame_pitch, planes, stride, pitch, frame_pitch, w, h, d_weights, d_weights + 8129);
     return hipGetLastError();
 }
 
