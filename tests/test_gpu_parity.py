@@ -298,6 +298,15 @@ def test_full_size_4k_frame(gpu_ctx, weights_blob):
     r_out, r_pre = oracle.forward_y(y, weights_blob)
     assert hashlib.sha256(r_out.tobytes()).hexdigest() == pins["oracle_sha256"]
     assert int((out != r_out).sum()) == pins["u8_mismatches_between_them"]
+    # SRCNN_MODE_EXACT reproduces the reference arithmetic bit for bit at full size
+    gpu_ctx.set_mode(S.MODE_EXACT)
+    try:
+        e_pre = np.empty((h, w), np.float32)
+        e_out = gpu_ctx.forward_y(y, preclamp=e_pre)
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+    assert hashlib.sha256(e_out.tobytes()).hexdigest() == pins["oracle_sha256"]
+    assert np.array_equal(e_pre, r_pre)
     assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS
     check_u8(out, r_out, r_pre)
 
