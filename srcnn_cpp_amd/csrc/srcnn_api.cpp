@@ -541,15 +541,19 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         n_frames <= 0)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: bad arguments");
     if (c->mode == SRCNN_MODE_EXACT) {
+        // frame by frame through ONE 32-plane workspace (128 B/pixel), whatever the batch size
         const long pitch = (long)width * height;
-        if ((rc = reserve(c, c->planes, (size_t)n_frames * 32 * pitch * 4))) return rc;
+        if ((rc = reserve(c, c->planes, (size_t)32 * pitch * 4))) return rc;
         float *work = static_cast<float *>(c->planes.p);
-        HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, (long)src_frame_pitch, work, width, pitch,
-                                          32 * pitch, width, height, n_frames,
-                                          static_cast<const float *>(c->wraw.p), c->stream));
-        HIP_TRY(c, launch_conv55_exact(work, width, pitch, 32 * pitch, d_dst, d_preclamp, (long)dst_stride,
-                                       (long)dst_frame_pitch, width, height, n_frames,
-                                       static_cast<const float *>(c->wraw.p) + 7329, c->b3, c->stream));
+        for (int f = 0; f < n_frames; ++f) {
+            HIP_TRY(c, launch_conv99x11_exact(d_src + (size_t)f * src_frame_pitch, (long)src_stride, 0, work, width,
+                                              pitch, 0, width, height, 1, static_cast<const float *>(c->wraw.p),
+                                              c->stream));
+            HIP_TRY(c, launch_conv55_exact(work, width, pitch, 0, d_dst + (size_t)f * dst_frame_pitch,
+                                           d_preclamp ? d_preclamp + (size_t)f * dst_frame_pitch : nullptr,
+                                           (long)dst_stride, 0, width, height, 1,
+                                           static_cast<const float *>(c->wraw.p) + 7329, c->b3, c->stream));
+        }
         return SRCNN_OK;
     }
     StripParams p{};

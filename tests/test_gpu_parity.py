@@ -412,3 +412,25 @@ def test_random_shapes_and_strides(gpu_ctx, weights_blob):
             o2 = np.empty((h, w), np.uint8)
             gpu_ctx.conv55([buf[k, :, :w] for k in range(32)], o2, w3, b3)
             assert np.array_equal(o2, m_out), (w, h)
+
+
+def test_exact_mode_batch_on_device(gpu_ctx, weights_blob):
+    """SRCNN_MODE_EXACT on a device-resident batch (frames run one by one through a single
+    32-plane workspace): every frame bit-identical to the reference arithmetic."""
+    import torch
+    n, h, w = 4, 50, 170
+    frames = synth_batch(w, h, n, first_frame=30)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    d_pre = torch.zeros((n, h, w), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.set_mode(S.MODE_EXACT)
+    try:
+        gpu_ctx.forward_y_dev(d_in.data_ptr(), w, h * w, d_out.data_ptr(), w, h * w, w, h, n, d_pre.data_ptr())
+        gpu_ctx.synchronize()
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+    out, pre = d_out.cpu().numpy(), d_pre.cpu().numpy()
+    for k in range(n):
+        r_out, r_pre = oracle.forward_y(frames[k], weights_blob)
+        assert np.array_equal(out[k], r_out) and np.array_equal(pre[k], r_pre)
