@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t *__rest
 // pixel instead of 16.  Same integer arithmetic, bit-identical results.
 constexpr int RT = 8;        // output rows per workgroup
 constexpr int RMAX = 16;     // source rows a tile may span (host checks before choosing this kernel)
+constexpr int SMAX = 288;    // source columns a 256-wide tile may span
 
 __global__ __launch_bounds__(256) void resize_cubic_tiled_kernel(const uint8_t *__restrict__ src, long sstride,
                                                                  long spitch, int sw, int sh,
@@ -91,26 +92,31 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled_kernel(const uint8_t *
                                                                  const short *__restrict__ beta)
 {
     __shared__ int hbuf[RMAX][256];
-    const int dx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint8_t sbuf[RMAX][SMAX];   // the source rows of the tile (replicate border applied), bytes
+    const int dx0 = blockIdx.x * 256, dx = dx0 + threadIdx.x;
     const int dy0 = blockIdx.y * RT, dy1 = min(dy0 + RT, dh);
     const uint8_t *s = src + (long)blockIdx.z * spitch;
     const int r_lo = yofs[dy0] - 1, r_hi = yofs[dy1 - 1] + 2;     // unclamped source rows of this tile
-    const int dxc = min(dx, dw - 1);
-    const int x0 = xofs[dxc] - 1;
-    int a[4], xs[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        a[k] = alpha[4 * dxc + k];
-        xs[k] = min(max(x0 + k, 0), sw - 1);
+    const int c_lo = xofs[dx0] - 1, c_hi = xofs[min(dx0 + 255, dw - 1)] + 2;   // ... and columns
+    const int ncol = c_hi - c_lo + 1, nrow = r_hi - r_lo + 1;
+    // stage: consecutive lanes fetch consecutive source bytes of a row
+    for (int e = threadIdx.x; e < nrow * ncol; e += 256) {
+        const int rr = e / ncol, cc = e - rr * ncol;
+        sbuf[rr][cc] = s[(long)min(max(r_lo + rr, 0), sh - 1) * sstride + min(max(c_lo + cc, 0), sw - 1)];
     }
-    for (int r = r_lo; r <= r_hi; ++r) {
-        const uint8_t *row = s + (long)min(max(r, 0), sh - 1) * sstride;
+    __syncthreads();
+    const int dxc = min(dx, dw - 1);
+    const int x0 = xofs[dxc] - 1 - c_lo;
+    int a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = alpha[4 * dxc + k];
+    for (int rr = 0; rr < nrow; ++rr) {
         int t = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t += row[xs[k]] * a[k];
-        hbuf[r - r_lo][threadIdx.x] = t;
+        for (int k = 0; k < 4; ++k) t += sbuf[rr][x0 + k] * a[k];
+        hbuf[rr][threadIdx.x] = t;
     }
-    // every thread only reads back its own column: no barrier needed
+    // every thread only reads back its own hbuf column: no second barrier needed
     if (dx >= dw) return;
     for (int dy = dy0; dy < dy1; ++dy) {
         const int j = yofs[dy] - 1 - r_lo;
@@ -143,7 +149,8 @@ hipError_t launch_resize_cubic(const uint8_t *src, long sstride, long spitch, in
 {
     // a tile of RT output rows spans at most ceil(RT * sh / dh) + 4 source rows (4-tap support)
     const long span = ((long)RT * sh + dh - 1) / dh + 4;
-    if (span <= RMAX)
+    const long cspan = (256L * sw + dw - 1) / dw + 5;      // likewise for 256 output columns
+    if (span <= RMAX && cspan <= SMAX)
         hipLaunchKernelGGL(resize_cubic_tiled_kernel, dim3((dw + 255) / 256, (dh + RT - 1) / RT, n_planes), dim3(256),
                            0, st, src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, xofs, alpha, yofs, beta);
     else
