@@ -196,7 +196,8 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 /* ---- introspection for the bench / tests ---------------------------------- */
 
 /* Launch geometry the fused kernel would use for (width,height,n_frames):
- * out[0]=workgroups, out[1]=rows per segment, out[2]=strips, out[3]=segments,
+ * out[0]=workgroups, out[1]=rows per segment (the tallest one when a single plane is cut into
+ * unequal work items), out[2]=strips, out[3]=segments per strip (rounded up),
  * out[4]=LDS bytes per workgroup, out[5]=threads per workgroup. */
 int srcnn_query_plan(srcnn_ctx *ctx, int width, int height, int n_frames, int out[6]);
 

@@ -47,6 +47,10 @@ struct srcnn_ctx {
     DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
     int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
     // second lane of the host-frame pipeline (srcnn_forward_y_frames)
+    // explicit work items of single-round launches (build_items), cached per geometry
+    DevBuf items;
+    int items_key[5] = {0, 0, 0, 0, 0};
+    int items_count = 0;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
@@ -197,6 +201,93 @@ Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo)
 
 bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0 || h <= 0 || stride < (size_t)w; }
 
+// Explicit work items for a launch that fits the GPU in ONE round with two workgroups per CU.
+// The hardware hands the first n_cu blocks wave slot 0 of every CU; the MFMA pipe is arbitrated by
+// age, so those run faster than the block that joins them later (tools/diag_stamps.py).  Exactly
+// 2*n_cu items are made: every strip is cut into k or k+1 segments, the "fast" ones (first n_cu
+// blocks) (1+skew) tall, the "slow" ones (1-skew) tall, so that all slots are used and the two
+// workgroups of a CU finish together.  Placement only affects speed; the items tile the rows exactly.
+// Returns {strip, row_begin, row_end} triples in block order; empty when the geometry does not
+// qualify (the regular grid is used instead).
+std::vector<int> plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct)
+{
+    const std::vector<int> none;
+    const int rows = row_end - row_begin, slots = 2 * n_cu;
+    if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu || slots / n_strips < 2 ||
+        rows / (slots / n_strips + 1) < 24)
+        return none;
+    const int kbase = slots / n_strips, kextra = slots % n_strips;      // strips [0,kextra) get kbase+1 items
+    std::vector<int> k(n_strips), a(n_strips);
+    int fast_total = 0;
+    for (int s = 0; s < n_strips; ++s) {
+        k[s] = kbase + (s < kextra ? 1 : 0);
+        a[s] = k[s] / 2;
+        fast_total += a[s];
+    }
+    for (int s = 0; fast_total < n_cu && s < n_strips; ++s)              // odd counts first, then any
+        if (k[s] % 2 == 1 && a[s] < k[s] - 1) { ++a[s]; ++fast_total; }
+    for (int s = 0; fast_total < n_cu && s < n_strips; ++s)
+        if (a[s] < k[s] - 1) { ++a[s]; ++fast_total; }
+    if (fast_total != n_cu) return none;
+    const double d = skew_pct / 100.0;
+    std::vector<std::vector<int>> bounds(n_strips);
+    for (int s = 0; s < n_strips; ++s) {
+        const int b = k[s] - a[s];
+        const double u = rows / (a[s] * (1.0 + d) + b * (1.0 - d));
+        bounds[s].resize(k[s] + 1);
+        for (int j = 0; j <= k[s]; ++j) {
+            const double y = j <= a[s] ? j * (1.0 + d) * u : a[s] * (1.0 + d) * u + (j - a[s]) * (1.0 - d) * u;
+            bounds[s][j] = row_begin + std::min(rows, std::max(0, (int)std::lround(y)));
+        }
+        bounds[s][0] = row_begin;
+        bounds[s][k[s]] = row_end;
+        for (int j = 1; j <= k[s]; ++j)
+            if (bounds[s][j] <= bounds[s][j - 1]) return none;          // degenerate: regular grid instead
+    }
+    // Block i and block n_cu + i share a CU (measured, tools/diag_stamps.py): pair the tallest fast
+    // item with the shortest slow one so that every CU carries the same number of rows.
+    struct Item { int strip, y0, y1; };
+    std::vector<Item> fast, slow;
+    for (int s = 0; s < n_strips; ++s)
+        for (int j = 0; j < k[s]; ++j)
+            (j < a[s] ? fast : slow).push_back({s, bounds[s][j], bounds[s][j + 1]});
+    std::stable_sort(fast.begin(), fast.end(), [](const Item &x, const Item &y) { return x.y1 - x.y0 > y.y1 - y.y0; });
+    std::stable_sort(slow.begin(), slow.end(), [](const Item &x, const Item &y) { return x.y1 - x.y0 < y.y1 - y.y0; });
+    std::vector<int> items;
+    items.reserve(3 * (size_t)slots);
+    for (const Item &it : fast) items.insert(items.end(), {it.strip, it.y0, it.y1});
+    for (const Item &it : slow) items.insert(items.end(), {it.strip, it.y0, it.y1});
+    return (int)items.size() == 3 * slots ? items : none;
+}
+
+int skew_percent()
+{
+    static const char *env_skew = std::getenv("SRCNN_DEBUG_SKEW");     // experiment knob; 0 = regular grid
+    return env_skew ? std::atoi(env_skew) : 10;
+}
+
+// Device copy of plan_items(), cached for the last geometry.  *n_items = 0: use the regular grid.
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int *n_items)
+{
+    *n_items = 0;
+    const int key[5] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu};
+    if (c->items_key[0] && std::memcmp(key, c->items_key, sizeof(key)) == 0) {
+        *n_items = c->items_count;
+        return SRCNN_OK;
+    }
+    const std::vector<int> items = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3]);
+    if (!items.empty()) {
+        int rc;
+        HIP_TRY(c, hipDeviceSynchronize());                             // an earlier launch may still read the table
+        if ((rc = reserve(c, c->items, items.size() * sizeof(int)))) return rc;
+        HIP_TRY(c, hipMemcpy(c->items.p, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    std::memcpy(c->items_key, key, sizeof(key));
+    c->items_count = (int)items.size() / 3;
+    *n_items = c->items_count;
+    return SRCNN_OK;
+}
+
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
@@ -211,22 +302,17 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.seg_rows = pl.seg_rows;
     p.n_strips = pl.n_strips;
     p.n_segs = pl.n_segs;
-    p.n_tall = 0;
-    p.tall_rows = 0;
-    // Skewed split (see srcnn_mfma.hip): one frame, one round, two workgroups on (almost) every CU.
-    // 10 % measured best on MI355X (profiles/r01/skew_sweep.txt); SRCNN_DEBUG_SKEW=0 turns it off.
-    static const char *env_skew = std::getenv("SRCNN_DEBUG_SKEW");
-    const int skew_pct = env_skew ? std::atoi(env_skew) : 10;
-    const long wgs = (long)pl.n_strips * pl.n_segs;
-    if (skew_pct > 0 && mode != MODE_L12 && n_frames == 1 && pl.n_segs >= 2 && pl.n_segs % 2 == 0 &&
-        wgs <= 2L * c->n_cu && wgs > c->n_cu && (long)pl.n_strips * (pl.n_segs / 2) <= c->n_cu) {
-        const int rows = p.row_end - p.row_begin, nt = pl.n_segs / 2;
-        const int tall = pl.seg_rows + (pl.seg_rows * skew_pct + 50) / 100;
-        const int rest = rows - nt * tall;
-        if (rest >= nt) {
-            p.n_tall = nt;
-            p.tall_rows = tall;
-            p.seg_rows = (rest + nt - 1) / nt;          // short segments cover the remainder
+    p.items = nullptr;
+    int grid_items = 0;
+    // One plane that fits the GPU in a single round: size the work items by the speed of the wave
+    // slot they will land in and use every slot (build_items).
+    if (mode != MODE_L12 && n_frames == 1) {
+        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, &grid_items);
+        if (rc) return rc;
+        if (grid_items > 0) {
+            p.items = static_cast<const int *>(c->items.p);
+            p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
+            p.n_segs = grid_items;
         }
     }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
@@ -349,7 +435,7 @@ void srcnn_destroy(srcnn_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
-                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables})
+                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->items})
         release(*b);
     for (int k = 0; k < 2; ++k) {
         release(c->lane_in[k]);
@@ -418,6 +504,15 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
+    if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
+        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent());
+        if (!items.empty()) {
+            out[0] = (int)items.size() / 3;
+            out[1] = 0;
+            for (size_t i = 0; i < items.size(); i += 3) out[1] = std::max(out[1], items[i + 2] - items[i + 1]);
+            out[3] = (out[0] + pl.n_strips - 1) / pl.n_strips;
+        }
+    }
     out[4] = (int)strip_lds_bytes(MODE_FUSED);
     out[5] = NTHREADS;
     return SRCNN_OK;

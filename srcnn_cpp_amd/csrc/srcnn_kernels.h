@@ -58,7 +58,8 @@ struct StripParams {
     int width, height;              // full image (border-replication domain)
     int row_begin, row_end;         // output rows produced by this launch
     int seg_rows, n_strips, n_segs; // workgroup decomposition
-    int n_tall, tall_rows;          // skewed split (single-round launches): segments [0,n_tall) have tall_rows rows
+    const int *items;               // optional explicit work items {strip, row_begin, row_end} per block
+                                    // (single-round launches, see build_items()); nullptr = regular grid
     int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
 };
 

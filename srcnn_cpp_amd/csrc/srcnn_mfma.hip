@@ -94,18 +94,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     // 12 halo columns / rows of Y -- instead of every 8th one.  Bijective for any grid size; speed
     // only (the input is 1 B/pixel, so the effect on this MFMA-bound kernel is within noise).
     int bid = blockIdx.x;
-    int strip, seg, frame = 0;
-    if (p.n_tall > 0) {
-        // Skewed split for launches that fit the GPU in one round with two workgroups per CU: the
-        // hardware fills every CU's first wave slots with the first n_cu blocks and arbitrates the
-        // MFMA pipe by age, so the earlier-dispatched workgroup of a CU runs ~12 % faster than the
-        // later one.  Hand the TALL segments to the low block ids so both finish together
-        // (measured dispatch order, profiles/r01; speed only -- any placement computes the same plane).
-        const int n_tall_items = p.n_strips * p.n_tall;
-        const bool tall = bid < n_tall_items;
-        const int j = tall ? bid : bid - n_tall_items;
-        strip = j % p.n_strips;
-        seg = (tall ? 0 : p.n_tall) + j / p.n_strips;
+    int strip, frame = 0, ys, ye;
+    if (p.items) {
+        // Single-round launch: the host hands every block its own {strip, row range}.  Block ids are
+        // the hardware dispatch order -- the first n_cu blocks take wave slot 0 of every CU and win the
+        // age-based MFMA arbitration, so they run ~12 % faster than the block that joins them later --
+        // and the host sizes the items accordingly (measured dispatch order, profiles/r01; speed only:
+        // any placement computes the same plane).
+        const int *it = p.items + 3 * bid;
+        strip = it[0];
+        ys = it[1];
+        ye = it[2];
     } else {
         if (!(p.tune & 8)) {
             const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -113,21 +112,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         }
         strip = bid % p.n_strips;
         bid /= p.n_strips;
-        seg = bid % p.n_segs;
+        const int seg = bid % p.n_segs;
         frame = bid / p.n_segs;
+        ys = p.row_begin + seg * p.seg_rows;
+        ye = min(ys + p.seg_rows, p.row_end);
     }
 
     const int xs = strip * OWM;        // first output column of the strip
     const int gx0 = xs - HALO;         // image column of feature column xi = 0
-    int ys, ye;
-    if (p.n_tall > 0) {
-        const bool tall = seg < p.n_tall;
-        ys = p.row_begin + (tall ? seg * p.tall_rows : p.n_tall * p.tall_rows + (seg - p.n_tall) * p.seg_rows);
-        ye = min(ys + (tall ? p.tall_rows : p.seg_rows), p.row_end);
-    } else {
-        ys = p.row_begin + seg * p.seg_rows;
-        ye = min(ys + p.seg_rows, p.row_end);
-    }
     const int f_lo = max(ys - HALO, 0);
     const int f_hi = min(ye + HALO, H);   // feature rows [f_lo, f_hi) are computed
 
@@ -427,8 +419,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             o[3] = dg_l1;
             o[4] = dg_l23;
             o[5] = dg_bar;
-            o[6] = (unsigned long long)(f_hi - f_lo);
-            o[7] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+            o[6] = (unsigned long long)(f_hi - f_lo) | ((dg_r0 & 0xffffffffull) << 32);     // rows | start time
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |  // HW_ID
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);  // XCC_ID
         }
     }
 }
@@ -440,6 +433,7 @@ size_t strip_lds_bytes(int /*mode*/)
 
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {
+    // with explicit items, n_segs carries the number of items per strip-set: n_strips * n_segs = item count
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
     const size_t lds = strip_lds_bytes(mode) + lds_pad;

@@ -270,6 +270,36 @@ def test_row_stripes_equal_whole_image(gpu_ctx, weights_blob, n_stripes):
     assert np.array_equal(out, whole)
 
 
+@pytest.mark.parametrize("w,h", [(3840, 2160), (1920, 1080), (2000, 1203), (992, 1700), (7680, 4320), (125, 6400)])
+def test_single_plane_work_items_equal_batch_grid(gpu_ctx, weights_blob, w, h):
+    """Launch-geometry independence at full sizes: a plane launched alone is cut into
+    unequal per-block work items sized for the wave slot they land in
+    (csrc/srcnn_api.cpp plan_items); inside a batch the same plane runs on the regular
+    strip x segment grid.  Both must give the same bytes -- any gap or overlap in the item
+    table shows up here.  A row stripe of the plane (row_begin != 0) is checked too."""
+    torch = _torch()
+    y = synth_luma(w, h, frame=3)
+    d_in = torch.from_numpy(np.stack([y, y])).cuda()
+    d_batch = torch.zeros_like(d_in)
+    d_one = torch.full((h, w), 7, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.forward_y_dev(d_in.data_ptr(), w, h * w, d_batch.data_ptr(), w, h * w, w, h, 2)
+    gpu_ctx.forward_y_dev(d_in.data_ptr(), w, h * w, d_one.data_ptr(), w, h * w, w, h, 1)
+    gpu_ctx.synchronize()
+    batch = d_batch.cpu().numpy()
+    one = d_one.cpu().numpy()
+    assert np.array_equal(batch[0], batch[1])
+    assert np.array_equal(one, batch[0])
+    plan1, plan2 = gpu_ctx.query_plan(w, h, 1), gpu_ctx.query_plan(w, h, 2)
+    assert plan1["workgroups"] >= 1 and plan2["workgroups"] >= 2
+    r0, r1 = h // 3 + 1, h - h // 5
+    d_stripe = torch.full((r1 - r0, w), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.forward_y_rows_dev(d_in.data_ptr(), w, 0, d_stripe.data_ptr(), w, r0, w, h, r0, r1)
+    gpu_ctx.synchronize()
+    assert np.array_equal(d_stripe.cpu().numpy(), one[r0:r1])
+
+
 def test_full_size_4k_frame(gpu_ctx, weights_blob):
     """configs[1] at full size (3840x2160).  The whole frame is checked bitwise
     against the FMA-order model; parity with the reference arithmetic is checked
