@@ -24,6 +24,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6     # dense f16/bf16: v_mfma_f32_32x32x16_f16 = 32,768 FLOP / 32 clk / SIMD x 1024 SIMD x 2.4 GHz
 
 
 def cpu_baseline(width, height, target_s=12.0):
@@ -70,7 +71,10 @@ def main():
     ap.add_argument("--path", choices=["fused", "unfused", "host", "pipeline"], default="fused",
                     help="fused: one kernel, u8 in/out (default); unfused: layer-1/2 kernel -> 32 f32 planes in "
                          "HBM -> layer-3 kernel; host: srcnn_forward_y on pageable host buffers (PCIe-inclusive)")
-    ap.add_argument("--mode", choices=["mfma", "exact"], default="mfma")
+    ap.add_argument("--mode", choices=["mfma", "exact", "split16"], default="mfma",
+                    help="mfma: float32 MFMA (default, the headline); exact: reference arithmetic on the vector ALU; "
+                         "split16: opt-in f16-MFMA mode with (hi, lo) operand splitting (SURVEY.md 8f rank 4) -- "
+                         "never the headline number")
     ap.add_argument("--workload", choices=["frames", "stripe"], default="frames",
                     help="frames: independent planes per rank, no collective, weak scaling (default); "
                          "stripe: ONE width x height plane row-striped over the ranks with a 6-row "
@@ -111,6 +115,8 @@ def main():
     ctx.set_weights_blob(S.load_weights())
     if args.mode == "exact":
         ctx.set_mode(S.MODE_EXACT)
+    elif args.mode == "split16":
+        ctx.set_mode(S.MODE_SPLIT16)
     # a real (non-null) stream that both torch's events and the HIP kernels use
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -229,6 +235,15 @@ def main():
                          "mfma_busy_frac_pmc": mfma_busy, "kernel_ms": round(kern_ms, 4),
                          "flop_per_pixel": S.FLOP_PER_PIXEL},
         }
+        if args.mode == "split16":
+            # opt-in mode: priced against the dense f16 MFMA peak with the same ALGORITHMIC flops; the
+            # kernel executes 42 MFMA x 32x32x16 per 32 pixels = 43,008 flop/pixel (2-3 f16 products per MAC)
+            peak16 = PEAK_F16_MFMA_TFLOPS
+            out["dtype"] = "f16x2-split operands, f32 accumulate"
+            out["roofline"].update({"peak": peak16, "frac": round(achieved / peak16, 4),
+                                    "executed_mfma_flop_per_pixel": 43008,
+                                    "executed_frac": round(achieved * 43008 / S.FLOP_PER_PIXEL / peak16, 4),
+                                    "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H)
         print(json.dumps(out), flush=True)

@@ -56,8 +56,15 @@ enum {
  *   SRCNN_MODE_EXACT reference arithmetic reproduced exactly on the vector
  *                    ALU (rounded multiply then rounded add, double 25-term
  *                    sums in layer 3): bit-identical to the reference CPU
- *                    path, roughly 3x slower (no FMA: two VALU operations per MAC). */
-enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1 };
+ *                    path, roughly 3x slower (no FMA: two VALU operations per MAC).
+ *   SRCNN_MODE_SPLIT16 opt-in, outside the float32 north star:
+ *                    the fused forward pass (srcnn_forward_y*, srcnn_process_bgr*)
+ *                    on v_mfma_f32_32x32x16_f16 with every float32 operand split
+ *                    into an f16 (hi, lo) pair -- 22 significant bits, f32
+ *                    accumulation; same tolerance as SRCNN_MODE_MFMA, several
+ *                    times faster.  The per-filter entry points and the
+ *                    materialising path are unaffected (they run as in MFMA mode). */
+enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2 };
 
 typedef struct srcnn_ctx srcnn_ctx;
 

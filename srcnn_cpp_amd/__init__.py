@@ -28,7 +28,7 @@ import numpy as np
 __all__ = [
     "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
-    "MODE_MFMA", "MODE_EXACT", "FLOP_PER_PIXEL",
+    "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "FLOP_PER_PIXEL",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -37,6 +37,7 @@ _WEIGHTS_PATH = _PKG / "data" / "srcnn915_weights.f32"
 
 MODE_MFMA = 0
 MODE_EXACT = 1
+MODE_SPLIT16 = 2
 N_WEIGHTS = 8129
 # 2 x (64*81 + 32*64 + 32*25) MAC per output pixel
 FLOP_PER_PIXEL = 16064

@@ -22,6 +22,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno
 # multiply-then-add arithmetic: contraction to FMA must stay off there.
 UNITS = [
     ("srcnn_mfma.hip", []),
+    ("srcnn_split16.hip", []),
     ("srcnn_exact.hip", ["-ffp-contract=off"]),
     ("srcnn_pipeline.hip", []),
     ("srcnn_api.cpp", ["-x", "hip"]),

@@ -40,6 +40,7 @@ struct srcnn_ctx {
     bool has_weights = false;
     float b3 = 0.f;
     DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
+    DevBuf wfrag16; // split-f16 fragments (SRCNN_MODE_SPLIT16), S16_TABLE_BYTES
     DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
     // staging for the host-buffer entry points
     DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
@@ -132,6 +133,53 @@ void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *
     }
 }
 
+// Split-f16 A-operand fragments (srcnn_split16.hip).  A float w becomes the f16 pair
+// hi = f16(w * scale), lo = f16(w * scale - hi), both round-to-nearest.  Layer-1 weights are scaled
+// by 2^14 (the kernel stages y * 2^-14), the layer-1 bias is unscaled (its B operand is 1.0), layer
+// 2/3 weights are scaled by 2^14 and the kernel unscales the accumulators.
+void split16(float w, float scale, uint16_t *hi, uint16_t *lo)
+{
+    const float ws = w * scale;
+    const _Float16 h = (_Float16)ws;
+    const _Float16 l = (_Float16)(ws - (float)h);
+    std::memcpy(hi, &h, 2);
+    std::memcpy(lo, &l, 2);
+}
+
+void pack_fragments16(const float *w1 /*[64][81]*/, const float *b1, const float *w2 /*[32][64]*/,
+                      const float *b2, const float *w3 /*[32][25]*/, uint8_t *out /*S16_TABLE_BYTES*/)
+{
+    constexpr float SCALE = 16384.f;
+    uint16_t *tab = reinterpret_cast<uint16_t *>(out);
+    auto slot = [&](int frag, int l, int e) -> uint16_t * { return tab + ((size_t)frag * 64 + l) * 8 + e; };
+    for (int l = 0; l < 64; ++l) {
+        const int m = l & 31, h = l >> 5;
+        for (int e = 0; e < 8; ++e) {
+            for (int t = 0; t < 2; ++t)
+                for (int b = 0; b < 6; ++b) {
+                    const int tap = l1s_tap(b, h, e), c = 32 * t + m;
+                    const float w = tap < 0 ? 0.f : (tap == 81 ? b1[c] : w1[c * 81 + tap]);
+                    split16(w, tap == 81 ? 1.f : SCALE, slot((2 * t) * 6 + b, l, e), slot((2 * t + 1) * 6 + b, l, e));
+                }
+            // layer 2, k-block b: slot 8h+e is register 8(b&1)+e of layer-1 tile b>>1 on lane-half h,
+            // i.e. layer-1 channel 32(b>>1) + acc_row(8(b&1)+e, h); row m = layer-2 channel m
+            for (int b = 0; b < 4; ++b) {
+                const int c1 = 32 * (b >> 1) + acc_row(8 * (b & 1) + e, h);
+                split16(w2[m * 64 + c1], SCALE, slot(S16_FRAG_L2 + b, l, e), slot(S16_FRAG_L2 + 4 + b, l, e));
+            }
+            // layer 3, k-block b: slot 8h+e is layer-2 channel acc_row(8b+e, h); row m = tap l3_row_tap(m)
+            for (int b = 0; b < 2; ++b) {
+                const int c2 = acc_row(8 * b + e, h), tap = l3_row_tap(m);
+                split16(tap >= 0 ? w3[c2 * 25 + tap] : 0.f, SCALE, slot(S16_FRAG_L3 + b, l, e),
+                        slot(S16_FRAG_L3 + 2 + b, l, e));
+            }
+        }
+    }
+    float *b2t = reinterpret_cast<float *>(out + (size_t)S16_NFRAG * 64 * 16);
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) b2t[h * 16 + r] = b2[acc_row(r, h)];
+}
+
 int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11,
                    const float *k55, float b55)
 {
@@ -153,14 +201,18 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     std::memcpy(raw.data() + 7329, w3, 800 * 4);
     for (int k = 0; k < 32; ++k)
         for (int i = 0; i < 64; ++i) raw[8129 + i * 32 + k] = w2[k * 64 + i];
+    std::vector<uint8_t> frag16(S16_TABLE_BYTES);
+    pack_fragments16(w1, b1, w2, b2, w3, frag16.data());
     int rc;
     if ((rc = reserve(c, c->wfrag, frag.size() * 4))) return rc;
+    if ((rc = reserve(c, c->wfrag16, frag16.size()))) return rc;
     if ((rc = reserve(c, c->sink, 1 << 20))) return rc;   // scratch words (+ diagnostics in debug builds)
     if ((rc = reserve(c, c->wraw, raw.size() * 4))) return rc;
     // synchronous copies: the host vectors die at return
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->wfrag.p, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->wraw.p, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->wfrag16.p, frag16.data(), frag16.size(), hipMemcpyHostToDevice));
     c->b3 = b55;
     return SRCNN_OK;
 }
@@ -316,6 +368,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         }
     }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
+    p.wfrag16 = static_cast<const uint32_t *>(c->wfrag16.p);
     p.sink = static_cast<float *>(c->sink.p);
     p.b3 = c->b3;
     // undocumented experiment knobs (never set in production)
@@ -323,7 +376,8 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
     p.tune = env_tune ? std::atoi(env_tune) : 0;
     const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
-    HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
+    if (mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16) HIP_TRY(c, launch_split16(p, n_frames, c->stream));
+    else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     return SRCNN_OK;
 }
 
@@ -435,7 +489,7 @@ void srcnn_destroy(srcnn_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
-                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->items})
+                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->items, &c->wfrag16})
         release(*b);
     for (int k = 0; k < 2; ++k) {
         release(c->lane_in[k]);
@@ -452,7 +506,8 @@ const char *srcnn_last_error(const srcnn_ctx *c) { return c ? c->err : "null con
 
 int srcnn_set_mode(srcnn_ctx *c, int mode)
 {
-    if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT)) return SRCNN_ERR_INVALID;
+    if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT && mode != SRCNN_MODE_SPLIT16))
+        return SRCNN_ERR_INVALID;
     c->mode = mode;
     return SRCNN_OK;
 }

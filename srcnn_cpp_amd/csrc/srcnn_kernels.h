@@ -38,6 +38,26 @@ __host__ __device__ constexpr int l3_row_tap(int i)
     return (r < 15 && n < 5) ? 5 * m + n : -1;
 }
 
+// ---- split-f16 variant (srcnn_split16.hip): A-operand fragments of v_mfma_f32_32x32x16_f16 ----
+// [S16_NFRAG][64 lanes][8 halfs]: L1 (tile t, part s = hi|lo, k-block b) at (2t+s)*6+b, L2 (s, b) at
+// S16_FRAG_L2 + 4s+b, L3 (s, b) at S16_FRAG_L3 + 2s+b; then float b2[2 lane-halves][16 registers].
+constexpr int S16_FRAG_L2 = 24, S16_FRAG_L3 = 32, S16_NFRAG = 36;
+constexpr size_t S16_TABLE_BYTES = (size_t)S16_NFRAG * 64 * 16 + 2 * 16 * sizeof(float);
+// Layer-1 K slot (k-block b, lane-half h, element e) -> tap 9*i+jj of the 9x9 window, 81 = the bias
+// slot (B operand 1.0), -1 = padding (zero weight).  Register n = 4b + e/2 of the lane holds the f16
+// pair (e even, e odd): n < 20 -> window row n/5 + 5h, columns 2(n%5), 2(n%5)+1; n = 20..22 -> row 4,
+// columns 4h + 2(n-20) + (0,1), of which half 0 owns 0..3 and half 1 owns 4..8; n = 23 -> bias.
+__host__ __device__ constexpr int l1s_tap(int b, int h, int e)
+{
+    const int n = 4 * b + e / 2, u = e & 1;
+    if (n < 20) return (2 * (n % 5) + u < 9) ? 9 * (n / 5 + 5 * h) + 2 * (n % 5) + u : -1;
+    if (n < 23) {
+        const int jj = 4 * h + 2 * (n - 20) + u;
+        return (h == 0 ? jj <= 3 : (jj >= 4 && jj <= 8)) ? 36 + jj : -1;
+    }
+    return (u == 0 && h == 0) ? 81 : -1;
+}
+
 struct StripParams {
     // layer-1 input (MODE_FUSED, MODE_L12)
     const uint8_t *src;
@@ -53,6 +73,7 @@ struct StripParams {
     long dst_stride, dst_frame_pitch;
     int dst_row0;
     const float *wfrag;
+    const uint32_t *wfrag16;        // split-f16 fragments (SRCNN_MODE_SPLIT16), else unused
     float *sink;                    // >= 128 floats of scratch for predicated-off stores
     float b3;
     int width, height;              // full image (border-replication domain)
@@ -65,6 +86,9 @@ struct StripParams {
 
 size_t strip_lds_bytes(int mode);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
+
+size_t split16_lds_bytes();
+hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream);
 
 // ---- exact (vector-ALU, reference arithmetic) kernels (srcnn_exact.hip) ----
 hipError_t launch_conv99_exact(const uint8_t *src, long sstride, float *dst, long dstride,

@@ -1,0 +1,328 @@
+// srcnn_split16.hip -- opt-in SPLIT-F16 variant of the fused strip kernel (SRCNN_MODE_SPLIT16).
+//
+// a lower-precision-MFMA mode, outside the float32 north star and
+// never the default.  Same path as srcnn_mfma.hip MODE_FUSED -- Convolution99x11 + Convolution55
+// (src/srcnn.cpp:254-325, :189-243), u8 luma in, u8 luma out, same strip / row-segment walk, same
+// layer-3 tap-partial scheme -- but the three contractions run on v_mfma_f32_32x32x16_f16
+// (16x the f32 MFMA rate) with every float32 operand SPLIT into two f16 numbers so that the
+// result stays at float32-level accuracy:
+//
+//   w = w_hi + w_lo   (host, round-to-nearest; |w - w_hi - w_lo| <= 2^-22 |w|)
+//   a = a_hi + a_lo   (kernel: a_hi = rtz_f16(a), a_lo = f16(a - a_hi), one v_fma_mixlo/hi_f16 each)
+//   w*a ~= w_hi*a_hi + w_lo*a_hi + w_hi*a_lo          (the dropped w_lo*a_lo is <= 2^-22 |w a|)
+//
+// f16 x f16 products are exact in the MFMA's f32 accumulation, so the only differences from the
+// f32 path are the 2^-22 truncations above and the summation order.  Layer 1 needs only two
+// products: its input is an 8-bit integer, exact in f16.  Scaling keeps every f16 factor in the
+// normal range (no reliance on denormals): Y is staged as y * 2^-14, W1/W2/W3 as w * 2^14; the
+// power-of-two factors cancel (layer 1) or are removed exactly in the epilogues (layers 2, 3).
+//
+//   L1  D1[64][32px] : K = 96 slots = 81 taps + bias slot + padding, x {hi, lo} x 2 tiles   24 MFMA
+//   L2  D2[32][32px] : K = 64, x {hi*hi, lo*hi, hi*lo}                                      12 MFMA
+//   L3  T [25][32px] : K = 32, x 3                                                            6 MFMA
+//
+// = 42 MFMA x 32 cycles per 32 pixels (vs 130 x 64 in the f32 kernel).  The accumulator layout of
+// 32x32x16 equals that of 32x32x2, so a layer's accumulators again feed the next layer's B operand
+// in place: k-block b takes registers 8(b&1)..+7 of tile b>>1, converted pairwise to packed f16.
+//
+// Layer-1 B operand: the Y ring is kept in LDS as f16, TWICE -- copy 0 as is, copy 1 shifted by
+// one column -- so that a lane reads two adjacent taps with one aligned ds_read_b32 whatever the
+// parity of its column.  Lane-half 0 feeds window rows 0-3 and taps 0-3 of row 4, lane-half 1 rows
+// 5-8 and taps 4-8 of row 4 (l1s_tap() in srcnn_kernels.h): both halves then use the same
+// immediate offsets from a per-lane base.
+//
+// Parity: tolerance-checked against the oracle (tests/test_gpu_split16.py); there is no bitwise CPU
+// model of this mode (the MFMA's internal f16 summation order is not documented).
+#include "srcnn_kernels.h"
+
+#include <type_traits>
+
+namespace srcnn {
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+
+constexpr int S16_YC = FW + 10;                 // staged ring columns: strip + 4 each side + the pair partner of tap 8
+constexpr int S16_RS = 144;                     // ring row pitch in halfs (even: rows stay dword aligned)
+constexpr int S16_CS = 2 * YR * S16_RS + 32;    // copy pitch in halfs (+16 dwords: the two copies hit disjoint banks)
+constexpr int S16_RING_BYTES = 2 * S16_CS * 2;
+
+__device__ __forceinline__ int clampi16(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+__device__ __forceinline__ void lds_barrier16() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float relu16(float x)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// (x0, x1) -> packed f16 pair hi = rtz(x), and lo = f16(x - hi): x - hi is exact in f32
+// (hi keeps the leading 11 bits of x), so hi + lo carries 22 bits of x.
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo)
+{
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+    hi = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][S16_RS]
+    float *fbuf = reinterpret_cast<float *>(smem + S16_RING_BYTES);       // [2][3][6][FW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+
+    constexpr int HALO = 2;
+    constexpr int OWM = FW - 2 * HALO;
+    const int W = p.width, H = p.height;
+
+    // work mapping: identical to srcnn_strip_kernel (srcnn_mfma.hip)
+    int bid = blockIdx.x;
+    int strip, frame = 0, ys, ye;
+    if (p.items) {
+        const int *it = p.items + 3 * bid;
+        strip = it[0];
+        ys = it[1];
+        ye = it[2];
+    } else {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        strip = bid % p.n_strips;
+        bid /= p.n_strips;
+        const int seg = bid % p.n_segs;
+        frame = bid / p.n_segs;
+        ys = p.row_begin + seg * p.seg_rows;
+        ye = min(ys + p.seg_rows, p.row_end);
+    }
+    const int xs = strip * OWM;
+    const int gx0 = xs - HALO;
+    const int f_lo = max(ys - HALO, 0);
+    const int f_hi = min(ye + HALO, H);
+
+    // ---- weight fragments -> registers: 36 fragments x 4 VGPRs (pack_fragments16) ----
+    const u32x4 *wf = reinterpret_cast<const u32x4 *>(p.wfrag16) + lane;
+    u32x4 w1[2][2][6], w2[2][4], w3[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) w1[t][s][b] = wf[((t * 2 + s) * 6 + b) * 64];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w2[s][b] = wf[(S16_FRAG_L2 + s * 4 + b) * 64];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) w3[s][b] = wf[(S16_FRAG_L3 + s * 2 + b) * 64];
+    float b2v[16];
+    {
+        const float *bt = reinterpret_cast<const float *>(p.wfrag16 + S16_NFRAG * 64 * 4) + half * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b2v[r] = bt[r];
+    }
+
+    // ---- layer-1 input: rolling window of Y rows as f16 (y * 2^-14) in LDS, two copies ----
+    // Ring column c is image column clamp(gx0-4+c) (replicate border, src/srcnn.cpp:266-280);
+    // copy 0 holds column c at element c, copy 1 at element c-1.  Row r lives in slots r&15 and
+    // (r&15)+16 so that a 9-row window is contiguous (as in srcnn_mfma.hip).
+    const uint8_t *srcf = p.src + (long)frame * p.src_frame_pitch;
+    const int ycol = clampi16(gx0 - 4 + tid, 0, W - 1);
+    auto load_y = [&](int r) -> uint8_t {
+        const int rr = clampi16(r, 0, H - 1) - p.src_row0;
+        return srcf[(long)rr * p.src_stride + ycol];
+    };
+    auto stage_y = [&](int r, uint8_t v) {
+        const int slot = r & (YR - 1);
+        const _Float16 hv = (_Float16)((float)v * 6.103515625e-05f);      // exact: 8-bit integer * 2^-14
+        _Float16 *c0 = ring + slot * S16_RS + tid;
+        c0[0] = hv;
+        c0[YR * S16_RS] = hv;
+        if (tid > 0) {
+            _Float16 *c1 = ring + S16_CS + slot * S16_RS + tid - 1;
+            c1[0] = hv;
+            c1[YR * S16_RS] = hv;
+        }
+    };
+    if (tid < S16_YC) {
+        uint8_t v[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v[q] = load_y(f_lo - 4 + q);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) stage_y(f_lo - 4 + q, v[q]);
+    }
+    __syncthreads();
+
+    const int xi = 32 * wave + j;
+    const int gx = gx0 + xi;
+
+    // ---- layer 3 epilogue: identical scheme to srcnn_mfma.hip; values carry the factor 2^14 of W3 ----
+    int xn[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) xn[n] = clampi16(clampi16(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+    const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+    float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    auto finalize = [&](int y, float acc, bool ok) {
+        const float v = __builtin_fmaf(acc, 6.103515625e-05f, p.b3);     // exact unscale, then + bias (one rounding)
+        const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
+        uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
+        *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
+        if constexpr (PRE) {
+            float *dp = ok ? p.pre + o : p.sink + 64 + lane;
+            *dp = v;
+        }
+    };
+    auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
+    auto vertical = [&](int f, const f32x16 &t) {
+        const int fplane = 3 * half * FW + xi;
+        if (f > 0) {
+            float *fo = ftile(f, 0) + fplane;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                fo[s * FW] = R[3][s] + t[5 * s + 4];
+                R[3][s] = R[2][s] + t[5 * s + 3];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[1][s] = R[0][s] + t[5 * s + 1];
+                R[0][s] = t[5 * s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                R[0][s] = t[5 * s];
+                R[1][s] = t[5 * s] + t[5 * s + 1];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[3][s] = 0.f;
+            }
+        }
+        if (f == H - 1) {
+            float *f1 = ftile(f, 1) + fplane, *f2 = ftile(f, 2) + fplane;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                f1[s * FW] = R[3][s] + t[5 * s + 4];
+                f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
+            }
+        }
+    };
+    auto horizontal = [&](int g, int slot) {
+        const float *fr = ftile(g, slot);
+        float acc = fr[xn[0]];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) acc += fr[n * FW + xn[n]];
+        const int y = g - 2 + slot;
+        finalize(y, acc, px_ok && (y >= ys) && (y < ye));
+    };
+
+    const int ring_lane = (xi & 1) * S16_CS + (xi & ~1);     // halfs; even -> dword aligned
+    for (int f = f_lo; f <= f_hi; ++f) {
+        const bool do_a = f < f_hi;
+        const int g = f - 1;
+        const bool hp = g >= f_lo;
+        if (!do_a) {
+            if (hp) {
+                const int nslots = (g == H - 1) ? 3 : 1;
+                for (int slot = 0; slot < nslots; ++slot) horizontal(g, slot);
+            }
+            break;
+        }
+        unsigned ynext = 0;
+        if (tid < S16_YC) ynext = load_y(f + 5);
+
+        // ---------------- layer 1: 24 MFMA -----------------------------------------------------
+        const unsigned *yb = reinterpret_cast<const unsigned *>(ring + ring_lane + ((f - 4) & (YR - 1)) * S16_RS);
+        const unsigned *ybH = yb + half * (5 * S16_RS / 2);          // rows 0-3 | rows 5-8
+        const unsigned *ybX = yb + 4 * (S16_RS / 2) + 2 * half;      // row 4: taps 0-5 | taps 4-9
+        unsigned bq[24];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) bq[rr * 5 + q] = ybH[rr * (S16_RS / 2) + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[20 + q] = ybX[q];
+        bq[23] = 0x00003C00u;                                        // (1.0, 0): the bias slot
+        f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const u32x4 bv = {bq[4 * b], bq[4 * b + 1], bq[4 * b + 2], bq[4 * b + 3]};
+            a0 = MFMA16(w1[0][0][b], bv, a0);
+            a1 = MFMA16(w1[1][0][b], bv, a1);
+            a0 = MFMA16(w1[0][1][b], bv, a0);
+            a1 = MFMA16(w1[1][1][b], bv, a1);
+        }
+        // the horizontal 5-term sum of the row completed one iteration ago
+        if (hp) horizontal(g, 0);
+
+        // ReLU (src/srcnn.cpp:304), split into f16 hi/lo pairs: the layer-2 B operands
+        unsigned h1[16], l1[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            split_pair(relu16(a0[2 * q]), relu16(a0[2 * q + 1]), h1[q], l1[q]);
+            split_pair(relu16(a1[2 * q]), relu16(a1[2 * q + 1]), h1[8 + q], l1[8 + q]);
+        }
+
+        // ---------------- layer 2: 12 MFMA -----------------------------------------------------
+        f32x16 d2 = {0};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const u32x4 bh = {h1[4 * b], h1[4 * b + 1], h1[4 * b + 2], h1[4 * b + 3]};
+            const u32x4 bl = {l1[4 * b], l1[4 * b + 1], l1[4 * b + 2], l1[4 * b + 3]};
+            d2 = MFMA16(w2[0][b], bh, d2);
+            d2 = MFMA16(w2[1][b], bh, d2);
+            d2 = MFMA16(w2[0][b], bl, d2);
+        }
+        // unscale (exact) + bias + ReLU (src/srcnn.cpp:316-319), split for layer 3
+        unsigned h2[8], l2[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            split_pair(relu16(__builtin_fmaf(d2[2 * q], 6.103515625e-05f, b2v[2 * q])),
+                       relu16(__builtin_fmaf(d2[2 * q + 1], 6.103515625e-05f, b2v[2 * q + 1])), h2[q], l2[q]);
+
+        // ---------------- layer 3 tap partials: 6 MFMA -----------------------------------------
+        f32x16 t = {0};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const u32x4 bh = {h2[4 * b], h2[4 * b + 1], h2[4 * b + 2], h2[4 * b + 3]};
+            const u32x4 bl = {l2[4 * b], l2[4 * b + 1], l2[4 * b + 2], l2[4 * b + 3]};
+            t = MFMA16(w3[0][b], bh, t);
+            t = MFMA16(w3[1][b], bh, t);
+            t = MFMA16(w3[0][b], bl, t);
+        }
+        vertical(f, t);
+
+        asm volatile("" : "+v"(ynext));
+        if (tid < S16_YC) stage_y(f + 5, (uint8_t)ynext);
+        lds_barrier16();
+    }
+}
+
+}  // namespace
+
+size_t split16_lds_bytes() { return (size_t)S16_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
+
+hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream)
+{
+    const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
+    const dim3 block(NTHREADS);
+    const size_t lds = split16_lds_bytes();
+    if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((srcnn_split16_kernel<false>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace srcnn
