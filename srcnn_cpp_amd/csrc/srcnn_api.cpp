@@ -41,6 +41,7 @@ struct srcnn_ctx {
     float b3 = 0.f;
     DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
     DevBuf wfrag16; // split-f16 fragments (SRCNN_MODE_SPLIT16), S16_TABLE_BYTES
+    bool split16_ok = false;   // the uploaded weights fit the f16 ranges of that mode (split16_range_ok)
     DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
     // staging for the host-buffer entry points
     DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
@@ -134,9 +135,8 @@ void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *
 }
 
 // Split-f16 A-operand fragments (srcnn_split16.hip).  A float w becomes the f16 pair
-// hi = f16(w * scale), lo = f16(w * scale - hi), both round-to-nearest.  Layer-1 weights are scaled
-// by 2^14 (the kernel stages y * 2^-14), the layer-1 bias is unscaled (its B operand is 1.0), layer
-// 2/3 weights are scaled by 2^14 and the kernel unscales the accumulators.
+// hi = f16(w * scale), lo = f16(w * scale - hi), both round-to-nearest; the power-of-two scales are
+// listed in the kernel's header comment.
 void split16(float w, float scale, uint16_t *hi, uint16_t *lo)
 {
     const float ws = w * scale;
@@ -149,7 +149,7 @@ void split16(float w, float scale, uint16_t *hi, uint16_t *lo)
 void pack_fragments16(const float *w1 /*[64][81]*/, const float *b1, const float *w2 /*[32][64]*/,
                       const float *b2, const float *w3 /*[32][25]*/, uint8_t *out /*S16_TABLE_BYTES*/)
 {
-    constexpr float SCALE = 16384.f;
+    constexpr float SCALE = 16384.f, SCALE1 = 2048.f;     // see the scale table in srcnn_split16.hip
     uint16_t *tab = reinterpret_cast<uint16_t *>(out);
     auto slot = [&](int frag, int l, int e) -> uint16_t * { return tab + ((size_t)frag * 64 + l) * 8 + e; };
     for (int l = 0; l < 64; ++l) {
@@ -159,7 +159,7 @@ void pack_fragments16(const float *w1 /*[64][81]*/, const float *b1, const float
                 for (int b = 0; b < 6; ++b) {
                     const int tap = l1s_tap(b, h, e), c = 32 * t + m;
                     const float w = tap < 0 ? 0.f : (tap == 81 ? b1[c] : w1[c * 81 + tap]);
-                    split16(w, tap == 81 ? 1.f : SCALE, slot((2 * t) * 6 + b, l, e), slot((2 * t + 1) * 6 + b, l, e));
+                    split16(w, tap == 81 ? 0.125f : SCALE1, slot((2 * t) * 6 + b, l, e), slot((2 * t + 1) * 6 + b, l, e));
                 }
             // layer 2, k-block b: slot 8h+e is register 8(b&1)+e of layer-1 tile b>>1 on lane-half h,
             // i.e. layer-1 channel 32(b>>1) + acc_row(8(b&1)+e, h); row m = layer-2 channel m
@@ -177,7 +177,36 @@ void pack_fragments16(const float *w1 /*[64][81]*/, const float *b1, const float
     }
     float *b2t = reinterpret_cast<float *>(out + (size_t)S16_NFRAG * 64 * 16);
     for (int h = 0; h < 2; ++h)
-        for (int r = 0; r < 16; ++r) b2t[h * 16 + r] = b2[acc_row(r, h)];
+        for (int r = 0; r < 16; ++r) b2t[h * 16 + r] = b2[acc_row(r, h)] * 0.0625f;
+}
+
+// SRCNN_MODE_SPLIT16 keeps its scaled activations below 1024 and its scaled weights inside f16
+// (srcnn_split16.hip).  Rigorous bounds for ANY 8-bit input: layer-1 channel c is at most
+// 255 * sum(max(w1,0)) + b1, layer-2 channel k at most sum(max(w2,0) * bound1) + b2.
+bool split16_range_ok(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3)
+{
+    float a1[64], wmax1 = 0.f, wmax23 = 0.f, a1max = 0.f, a2max = 0.f;
+    for (int c = 0; c < 64; ++c) {
+        double s = 0;
+        for (int t = 0; t < 81; ++t) {
+            s += std::max(w1[c * 81 + t], 0.f);
+            wmax1 = std::max(wmax1, std::fabs(w1[c * 81 + t]));
+        }
+        a1[c] = std::max(0.f, (float)(255.0 * s + b1[c]));
+        a1max = std::max(a1max, a1[c]);
+        wmax1 = std::max(wmax1, std::fabs(b1[c]) / 256.f);      // b1/8 must fit f16 as well
+    }
+    for (int k = 0; k < 32; ++k) {
+        double s = b2[k];
+        for (int i = 0; i < 64; ++i) {
+            s += (double)std::max(w2[k * 64 + i], 0.f) * a1[i];
+            wmax23 = std::max(wmax23, std::fabs(w2[k * 64 + i]));
+        }
+        a2max = std::max(a2max, (float)s);
+    }
+    for (int i = 0; i < 800; ++i) wmax23 = std::max(wmax23, std::fabs(w3[i]));
+    return std::isfinite(a1max) && std::isfinite(a2max) && a1max < 8.f * 1024.f && a2max < 16.f * 1024.f &&
+           wmax1 < 30.f && wmax23 < 3.9f;
 }
 
 int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11,
@@ -214,6 +243,7 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     HIP_TRY(c, hipMemcpy(c->wraw.p, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->wfrag16.p, frag16.data(), frag16.size(), hipMemcpyHostToDevice));
     c->b3 = b55;
+    c->split16_ok = split16_range_ok(w1, b1, w2, b2, w3);
     return SRCNN_OK;
 }
 
@@ -376,7 +406,12 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
     p.tune = env_tune ? std::atoi(env_tune) : 0;
     const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
-    if (mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16) HIP_TRY(c, launch_split16(p, n_frames, c->stream));
+    if (mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16) {
+        if (!c->split16_ok)
+            return fail(c, SRCNN_ERR_STATE, "SRCNN_MODE_SPLIT16: these weights exceed the f16 ranges of the mode "
+                                            "(layer maps must stay below 8192 / 16384 for 8-bit input); use SRCNN_MODE_MFMA");
+        HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
+    }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     return SRCNN_OK;
 }

@@ -88,7 +88,7 @@ size_t strip_lds_bytes(int mode);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 
 size_t split16_lds_bytes();
-hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream);
+hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 
 // ---- exact (vector-ALU, reference arithmetic) kernels (srcnn_exact.hip) ----
 hipError_t launch_conv99_exact(const uint8_t *src, long sstride, float *dst, long dstride,

@@ -13,9 +13,13 @@
 //
 // f16 x f16 products are exact in the MFMA's f32 accumulation, so the only differences from the
 // f32 path are the 2^-22 truncations above and the summation order.  Layer 1 needs only two
-// products: its input is an 8-bit integer, exact in f16.  Scaling keeps every f16 factor in the
-// normal range (no reliance on denormals): Y is staged as y * 2^-14, W1/W2/W3 as w * 2^14; the
-// power-of-two factors cancel (layer 1) or are removed exactly in the epilogues (layers 2, 3).
+// products: its input is an 8-bit integer, exact in f16.  Power-of-two scales (exact) keep every f16
+// factor in the normal range and every activation below 1024 (needed by relu_split_pair):
+//   Y staged as y * 2^-14, W1 as w * 2^11, b1 as b/8 (its B operand is 1.0)  -> layer-1 map / 8
+//   W2 as w * 2^14 -> accumulator = 2^11 * pre-bias; fma(acc, 2^-15, b2/16)  -> layer-2 map / 16
+//   W3 as w * 2^14 -> tap partials * 2^10, removed by the final fma(acc, 2^-10, b3).
+// The host checks at srcnn_set_weights that the weights allow this (rigorous bounds on the maps for
+// 8-bit input: < 8192 and < 16384 here 2065 and 8786) and refuses the mode otherwise.
 //
 //   L1  D1[64][32px] : K = 96 slots = 81 taps + bias slot + padding, x {hi, lo} x 2 tiles   24 MFMA
 //   L2  D2[32][32px] : K = 64, x {hi*hi, lo*hi, hi*lo}                                      12 MFMA
@@ -48,6 +52,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 
+constexpr float S16_UNSCALE_L2 = 3.0517578125e-05f;   // 2^-15
+constexpr float S16_UNSCALE_L3 = 9.765625e-04f;       // 2^-10
 constexpr int S16_YC = FW + 10;                 // staged ring columns: strip + 4 each side + the pair partner of tap 8
 constexpr int S16_RS = 144;                     // ring row pitch in halfs (even: rows stay dword aligned)
 constexpr int S16_CS = 2 * YR * S16_RS + 32;    // copy pitch in halfs (+16 dwords: the two copies hit disjoint banks)
@@ -64,18 +70,22 @@ __device__ __forceinline__ float relu16(float x)
     return r;
 }
 
-// (x0, x1) -> packed f16 pair hi = rtz(x), and lo = f16(x - hi): x - hi is exact in f32
-// (hi keeps the leading 11 bits of x), so hi + lo carries 22 bits of x.
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, unsigned &lo)
+// ReLU + split of two f32 values into packed f16 pairs: hi = max(rtz_f16(x), 0), lo = clamp(f16(x - hi), 0, 1).
+// x - hi is exact in f32 (hi keeps the leading 11 bits of x), so hi + lo carries 22 bits of x.  For
+// x < 0 both come out 0: hi by the packed max, lo because x - 0 < 0 clamps to 0 -- the ReLU of
+// src/srcnn.cpp:304,319 costs one packed instruction per pair.  The clamp's upper end is never reached:
+// the kernel keeps its activations below 1024 (scales in the header comment), so 0 <= x - hi < 1.
+__device__ __forceinline__ void relu_split_pair(float x0, float x1, unsigned &hi, unsigned &lo)
 {
     typedef __fp16 h2 __attribute__((ext_vector_type(2)));
     const h2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    hi = __builtin_bit_cast(unsigned, h);
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+    unsigned raw = __builtin_bit_cast(unsigned, h);
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(hi) : "v"(raw));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(lo) : "v"(hi), "v"(x1));
 }
 
-template <bool PRE>
+template <bool PRE, bool DIAG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
     const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
     float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto finalize = [&](int y, float acc, bool ok) {
-        const float v = __builtin_fmaf(acc, 6.103515625e-05f, p.b3);     // exact unscale, then + bias (one rounding)
+        const float v = __builtin_fmaf(acc, S16_UNSCALE_L3, p.b3);        // exact unscale, then + bias (one rounding)
         const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
         uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
         *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
@@ -230,6 +240,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
     };
 
     const int ring_lane = (xi & 1) * S16_CS + (xi & ~1);     // halfs; even -> dword aligned
+    // DIAG build only (SRCNN_DEBUG_TUNE & 2): cycle stamps -> p.sink, never an output
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    unsigned long long dg[6] = {0, 0, 0, 0, 0, 0}, dg_t0 = 0, dg_r0 = 0;
+    if constexpr (DIAG) {
+        dg_t0 = stamp();
+        dg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int f = f_lo; f <= f_hi; ++f) {
         const bool do_a = f < f_hi;
         const int g = f - 1;
@@ -241,8 +262,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
             }
             break;
         }
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        if constexpr (DIAG) s0 = stamp();
         unsigned ynext = 0;
-        if (tid < S16_YC) ynext = load_y(f + 5);
+        if (tid < S16_YC && !(p.tune & 32)) ynext = load_y(f + 5);
 
         // ---------------- layer 1: 24 MFMA -----------------------------------------------------
         const unsigned *yb = reinterpret_cast<const unsigned *>(ring + ring_lane + ((f - 4) & (YR - 1)) * S16_RS);
@@ -265,15 +288,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
             a0 = MFMA16(w1[0][1][b], bv, a0);
             a1 = MFMA16(w1[1][1][b], bv, a1);
         }
+        if constexpr (DIAG) { asm volatile("" :: "v"(a0[0]), "v"(a1[0])); s1 = stamp(); }
         // the horizontal 5-term sum of the row completed one iteration ago
-        if (hp) horizontal(g, 0);
+        if (hp && !(p.tune & 64)) horizontal(g, 0);
 
-        // ReLU (src/srcnn.cpp:304), split into f16 hi/lo pairs: the layer-2 B operands
+        // ReLU (src/srcnn.cpp:304) + split into f16 hi/lo pairs: the layer-2 B operands
         unsigned h1[16], l1[16];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            split_pair(relu16(a0[2 * q]), relu16(a0[2 * q + 1]), h1[q], l1[q]);
-            split_pair(relu16(a1[2 * q]), relu16(a1[2 * q + 1]), h1[8 + q], l1[8 + q]);
+            relu_split_pair(a0[2 * q], a0[2 * q + 1], h1[q], l1[q]);
+            relu_split_pair(a1[2 * q], a1[2 * q + 1], h1[8 + q], l1[8 + q]);
         }
 
         // ---------------- layer 2: 12 MFMA -----------------------------------------------------
@@ -286,12 +310,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
             d2 = MFMA16(w2[1][b], bh, d2);
             d2 = MFMA16(w2[0][b], bl, d2);
         }
-        // unscale (exact) + bias + ReLU (src/srcnn.cpp:316-319), split for layer 3
+        if constexpr (DIAG) { asm volatile("" :: "v"(d2[0])); s2 = stamp(); }
+        // rescale (exact) + bias, ReLU (src/srcnn.cpp:316-319) + split for layer 3
         unsigned h2[8], l2[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            split_pair(relu16(__builtin_fmaf(d2[2 * q], 6.103515625e-05f, b2v[2 * q])),
-                       relu16(__builtin_fmaf(d2[2 * q + 1], 6.103515625e-05f, b2v[2 * q + 1])), h2[q], l2[q]);
+            relu_split_pair(__builtin_fmaf(d2[2 * q], S16_UNSCALE_L2, b2v[2 * q]),
+                            __builtin_fmaf(d2[2 * q + 1], S16_UNSCALE_L2, b2v[2 * q + 1]), h2[q], l2[q]);
 
         // ---------------- layer 3 tap partials: 6 MFMA -----------------------------------------
         f32x16 t = {0};
@@ -303,11 +328,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
             t = MFMA16(w3[1][b], bh, t);
             t = MFMA16(w3[0][b], bl, t);
         }
-        vertical(f, t);
+        if constexpr (DIAG) { asm volatile("" :: "v"(t[0])); s3 = stamp(); }
+        if (!(p.tune & 64)) vertical(f, t);
 
         asm volatile("" : "+v"(ynext));
-        if (tid < S16_YC) stage_y(f + 5, (uint8_t)ynext);
-        lds_barrier16();
+        if (tid < S16_YC && !(p.tune & 32)) stage_y(f + 5, (uint8_t)ynext);
+        if constexpr (DIAG) s4 = stamp();
+        if (!(p.tune & 16)) lds_barrier16();
+        if constexpr (DIAG) {
+            const unsigned long long s5 = stamp();
+            dg[0] += s1 - s0; dg[1] += s2 - s1; dg[2] += s3 - s2; dg[3] += s4 - s3; dg[4] += s5 - s4;
+        }
+    }
+    if constexpr (DIAG) {
+        const unsigned long long t1 = stamp();
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) + ((long)blockIdx.x * NWAVES + wave) * 8;
+            o[0] = t1 - dg_t0;
+            o[1] = r1 - dg_r0;
+            o[2] = dg[0]; o[3] = dg[1]; o[4] = dg[2]; o[5] = dg[3];
+            o[6] = (unsigned long long)(f_hi - f_lo) | ((dg_r0 & 0xffffffffull) << 32);
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (dg[4] << 32);
+        }
     }
 }
 
@@ -315,12 +358,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
 
 size_t split16_lds_bytes() { return (size_t)S16_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
 
-hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream)
+hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
-    const size_t lds = split16_lds_bytes();
-    if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
+    const size_t lds = split16_lds_bytes() + lds_pad;
+    if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16_kernel<false, true>), grid, block, lds, stream, p);
+    else if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((srcnn_split16_kernel<false>), grid, block, lds, stream, p);
     return hipGetLastError();
 }

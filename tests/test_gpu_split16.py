@@ -156,3 +156,22 @@ def test_split16_deterministic_and_batched(split_ctx, weights_blob):
         assert np.array_equal(a[k], split_ctx.forward_y(frames[k]))
         r_out, r_pre = oracle.forward_y(frames[k], weights_blob)
         check_u8(a[k], r_out, r_pre)
+
+
+def test_split16_refuses_weights_outside_its_range(gpu_ctx, weights_blob):
+    """The mode's f16 ranges hold for the shipped model (rigorous bounds 2,065 and 8,786 on the
+    layer maps); weights that break them are refused loudly instead of overflowing."""
+    y = synth_luma(64, 32)
+    big = weights_blob.copy()
+    big[64:5248] *= 64.0                       # layer-1 weights x64: the map bound leaves the range
+    gpu_ctx.set_weights_blob(big)
+    gpu_ctx.set_mode(S.MODE_SPLIT16)
+    try:
+        with pytest.raises(S.SrcnnError) as e:
+            gpu_ctx.forward_y(y)
+        assert e.value.code == -5
+        gpu_ctx.set_mode(S.MODE_MFMA)
+        gpu_ctx.forward_y(y)                   # the float32 mode takes any weights
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+        gpu_ctx.set_weights_blob(weights_blob)
