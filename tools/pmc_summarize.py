@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 outputs of tools/profile_round.sh.
+
+usage: tools/pmc_summarize.py OUTDIR
+Writes OUTDIR/<mode>_4k_pmc_summary.json (counter means per dispatch of the strip kernel and the
+derived figures) and OUTDIR/<mode>_4k_kernel_stats.csv (per-kernel rows of the --stats pass).
+HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 byte-wide loads
+are reported at half their size (calibrated with tools/pmc_calib.hip: profiles/r01/pmc_calibration.txt),
+so reads = FETCH_SIZE * 1024 * 2, writes = WRITE_SIZE * 1024.
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+KERNEL = {"mfma": "srcnn_strip_kernel", "split16": "srcnn_split16_kernel"}
+for mode, kname in KERNEL.items():
+    sums, cnt = defaultdict(float), defaultdict(int)
+    grid = None
+    for f in glob.glob(os.path.join(out, f"pmc_{mode}_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if kname in row["Kernel_Name"]:
+                    sums[row["Counter_Name"]] += float(row["Counter_Value"])
+                    cnt[row["Counter_Name"]] += 1
+                    grid = int(row["Grid_Size"]) // int(row["Workgroup_Size"])
+    if not sums:
+        continue
+    mean = {k: sums[k] / cnt[k] for k in sums}
+    d = {}
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        d["hbm_read_bytes"] = mean["FETCH_SIZE"] * 1024 * 2
+        d["hbm_write_bytes"] = mean["WRITE_SIZE"] * 1024
+        d["hbm_bytes"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
+        d["mfma_busy_frac_of_simd_cycles"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (mean["GRBM_GUI_ACTIVE"] / 8)
+    if "SQ_INSTS_MFMA" in mean:
+        wave_rows = mean["SQ_INSTS_MFMA"] / (130 if mode == "mfma" else 42)
+        d["wave_rows"] = wave_rows
+        d["non_mfma_valu_per_wave_row"] = (mean.get("SQ_INSTS_VALU", 0) - mean["SQ_INSTS_MFMA"]) / wave_rows
+        d["lds_insts_per_wave_row"] = mean.get("SQ_INSTS_LDS", 0) / wave_rows
+        d["salu_insts_per_wave_row"] = mean.get("SQ_INSTS_SALU", 0) / wave_rows
+    stats_rows = []
+    avg_ns = None
+    for f in glob.glob(os.path.join(out, f"trace_{mode}", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            rows = list(csv.reader(fh))
+        stats_rows = rows
+        for r in rows[1:]:
+            if kname in r[0]:
+                avg_ns = float(r[3])
+    if stats_rows:
+        with open(os.path.join(out, f"{mode}_4k_kernel_stats.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(stats_rows)
+    summary = {"kernel": f"{kname} 3840x2160x1, {grid} workgroups", "rocprof_kernel_trace_avg_ns": avg_ns,
+               "counters_mean_per_dispatch": mean, "derived": d}
+    with open(os.path.join(out, f"{mode}_4k_pmc_summary.json"), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(mode, json.dumps(d), "avg_ns", avg_ns)

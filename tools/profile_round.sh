@@ -1,0 +1,38 @@
+#!/bin/bash
+# Profiles of one round on ONE MI355X (run through gpurun from the repo root):
+#   tools/profile_round.sh [OUTDIR]        (default gpurun_out/prof)
+# 1. the default bench line (with cpu_baseline), 2. rocprofv3 --kernel-trace --stats of the same command,
+# 3. PMC passes (one counter group per run, never together with a trace), for the float32 MFMA mode and
+# for the opt-in split-f16 mode, 4. the other configurations (tools/measure_all.sh), 5. in-kernel stamps.
+# tools/pmc_summarize.py turns the PMC csv files into profiles/rNN/*_pmc_summary.json.
+OUT=${1:-gpurun_out/prof}
+ROOT=$(pwd)
+mkdir -p $OUT
+export TMPDIR=/tmp
+python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --mode split16 --no-cpu-baseline > $OUT/bench_split16.json 2>> $OUT/bench_default.err
+python bench.py --mode split16 --frames 64 --steps 10 --no-cpu-baseline > $OUT/bench_split16_b64.json 2>> $OUT/bench_default.err
+for mode in mfma split16; do
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$mode -o trace -- \
+      python3 $ROOT/bench.py --mode $mode --steps 20 --warmup 3 --no-cpu-baseline ) > $OUT/trace_$mode.log 2>&1
+  for grp in "FETCH_SIZE" "WRITE_SIZE" \
+             "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
+    tag=$(echo $grp | cut -d' ' -f1)
+    ( cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pmc_${mode}_$tag -o pmc -- \
+        python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline ) > $OUT/pmc_${mode}_$tag.log 2>&1
+  done
+done
+tools/measure_all.sh $OUT/measurements.jsonl > /dev/null 2>&1
+python tools/diag_stamps.py > $OUT/diag_stamps_mfma.txt 2>&1
+DIAG_BLOCKS=512 python tools/diag_stamps.py > /dev/null 2>&1
+python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
+python tools/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
+python tools/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
+[ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
+[ -x build/mfma_probe ] && ./build/mfma_probe > $OUT/mfma_probe.txt 2>&1
+# keep the merge small: the raw per-dispatch csv files are summarised on the box
+python tools/pmc_summarize.py $OUT > $OUT/pmc_summarize.log 2>&1
+find $OUT -name "*counter_collection.csv" -size +2M -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
+ls -la $OUT
