@@ -208,11 +208,14 @@ def main():
         # command (separate --pmc runs, profiles/r01/README.md); they cannot be read live.
         traffic = mfma_busy = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists() and args.mode == "mfma" and not stripe:
+        if pmc.exists() and args.mode in ("mfma", "split16") and not stripe:
             try:
                 rec = json.loads(pmc.read_text())
-                traffic = rec.get(f"{args.path}_{W}x{H}x{F}")
-                mfma_busy = rec.get(f"{args.path}_{W}x{H}x{F}_mfma_busy_frac")
+                key = ("split16" if args.mode == "split16" and args.path == "fused" else args.path) + f"_{W}x{H}x{F}"
+                if args.mode == "split16" and args.path != "fused":
+                    key = "none"
+                traffic = rec.get(key)
+                mfma_busy = rec.get(key + "_mfma_busy_frac")
             except Exception:
                 traffic = mfma_busy = None
         out = {
