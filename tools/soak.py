@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised soak of the HIP path against the oracle (run on the GPU box; not part of pytest).
+
+usage: python tools/soak.py [seconds] [seed]
+Random plane sizes (biased to strip / unit / item-planner boundaries), padded strides, three
+content types; every result is checked: float32 MFMA mode bitwise against the FMA-order model and
+within tolerance of the reference arithmetic, split-f16 mode within tolerance, exact mode bitwise.
+"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+import oracle, srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_luma
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+blob = S.load_weights()
+ctx = S.Context(0); ctx.set_weights_blob(blob)
+TOL = 5e-3
+edges = [1, 2, 5, 9, 31, 32, 33, 123, 124, 125, 127, 128, 129, 247, 248, 249, 372, 373, 496, 497, 620]
+def dim(big):
+    r = rng.random()
+    if r < 0.5: return int(rng.choice(edges))
+    return int(rng.integers(1, big))
+n = 0; worst = {"mfma": 0.0, "split16": 0.0}; t0 = time.time()
+while time.time() - t0 < budget:
+    w, h = dim(900), dim(700)
+    if rng.random() < 0.1: h = int(rng.integers(1500, 6000)); w = int(rng.choice([124, 125, 248, 300]))   # item planner
+    kind = rng.integers(0, 3)
+    if kind == 0: y = synth_luma(w, h, frame=int(rng.integers(0, 50)))
+    elif kind == 1: y = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    else: y = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+    stride = w + int(rng.integers(0, 3)) * int(rng.integers(0, 40))
+    buf = np.zeros((h, stride), np.uint8); buf[:, :w] = y; yv = buf[:, :w]
+    r_out, r_pre = oracle.forward_y(y, blob)
+    m_out, m_pre = oracle.gpuorder_forward_y(y, blob)
+    scale = max(1.0, float(np.abs(r_pre).max()) / 255.0)
+    for name, mode in (("mfma", S.MODE_MFMA), ("split16", S.MODE_SPLIT16), ("exact", S.MODE_EXACT)):
+        if name == "exact" and w * h > 200000: continue
+        ctx.set_mode(mode)
+        pre = np.full((h, w), np.nan, np.float32)
+        out = ctx.forward_y(yv, preclamp=pre)
+        assert np.isfinite(pre).all(), (name, w, h)
+        if name == "exact":
+            assert np.array_equal(out, r_out) and np.array_equal(pre, r_pre), (name, w, h, kind)
+            continue
+        if name == "mfma":
+            assert np.array_equal(out, m_out) and np.array_equal(pre, m_pre), (name, w, h, kind)
+        e = float(np.abs(pre - r_pre).max())
+        worst[name] = max(worst[name], e / scale)
+        assert e <= TOL * scale, (name, w, h, kind, e)
+        d = np.abs(out.astype(int) - r_out.astype(int))
+        assert d.max() <= 1, (name, w, h, kind)
+        if d.any():
+            assert np.abs(r_pre - np.rint(r_pre))[d != 0].max() <= TOL * scale, (name, w, h, kind)
+    n += 1
+ctx.set_mode(S.MODE_MFMA)
+print(f"soak ok: {n} random planes in {time.time() - t0:.0f} s (seed {seed}); worst pre-clamp error / max(1, |ref|max/255): "
+      f"mfma {worst['mfma']:.2e}, split16 {worst['split16']:.2e}")
