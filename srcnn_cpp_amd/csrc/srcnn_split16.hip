@@ -354,15 +354,333 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripP
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined variant: ONE workgroup per CU (one wave per SIMD, 512 registers per lane).
+// With a single wave on the SIMD nothing else hides a wave's vector work, so the row loop is
+// pipelined inside the wave: while the vector chain of row f runs (split -> layer 2 -> split ->
+// layer 3), the 24 layer-1 MFMAs of row f+1 -- which depend on nothing in that chain -- are issued
+// between its steps.  Program order is the schedule: every MFMA is followed by at most one
+// relu_split_pair (4 vector instructions, what fits in the 24 free issue cycles of a 32-cycle f16
+// MFMA, tools/f16_probe.hip) and sched_barrier(0) keeps the compiler from regrouping.  Two
+// accumulator sets alternate between "being converted" and "being accumulated" (the loop is
+// unrolled by two), rows are staged two ahead so that the B operands of row f+2 are read before the
+// barrier that ends iteration f.
+constexpr int SP_RS = 264;                      // ring row pitch in halfs: every thread stages its own column
+constexpr int SP_CS = 2 * YR * SP_RS + 32;
+constexpr int SP_RING_BYTES = 2 * SP_CS * 2;
+
+template <bool PRE>
+__global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const StripParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][SP_RS]
+    float *fbuf = reinterpret_cast<float *>(smem + SP_RING_BYTES);        // [2][3][6][FW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;
+    const int half = lane >> 5;
+    constexpr int HALO = 2;
+    constexpr int OWM = FW - 2 * HALO;
+    const int W = p.width, H = p.height;
+
+    int bid = blockIdx.x;
+    int strip, frame = 0, ys, ye;
+    if (p.items) {
+        const int *it = p.items + 3 * bid;
+        strip = it[0];
+        ys = it[1];
+        ye = it[2];
+    } else {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        strip = bid % p.n_strips;
+        bid /= p.n_strips;
+        const int seg = bid % p.n_segs;
+        frame = bid / p.n_segs;
+        ys = p.row_begin + seg * p.seg_rows;
+        ye = min(ys + p.seg_rows, p.row_end);
+    }
+    const int xs = strip * OWM;
+    const int gx0 = xs - HALO;
+    const int f_lo = max(ys - HALO, 0);
+    const int f_hi = min(ye + HALO, H);
+
+    const u32x4 *wf = reinterpret_cast<const u32x4 *>(p.wfrag16) + lane;
+    u32x4 w1[2][2][6], w2[2][4], w3[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) w1[t][s][b] = wf[((t * 2 + s) * 6 + b) * 64];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w2[s][b] = wf[(S16_FRAG_L2 + s * 4 + b) * 64];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) w3[s][b] = wf[(S16_FRAG_L3 + s * 2 + b) * 64];
+    float b2v[16];
+    {
+        const float *bt = reinterpret_cast<const float *>(p.wfrag16 + S16_NFRAG * 64 * 4) + half * 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b2v[r] = bt[r];
+    }
+    // The weight fragments are only ever MFMA A operands: keep them in the accumulation-register half of
+    // the wave's 512 registers, so the 256 architectural VGPRs are free for everything the vector ALU touches.
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) asm volatile("" : "+a"(w1[t][s][b]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+a"(w2[s][b]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+a"(w3[s][b]));
+
+    // Y ring: as in srcnn_split16_kernel, but every thread stages its own column (columns >= FW+10
+    // are never read) so staging needs no predicate, and rows are staged two ahead.
+    const uint8_t *srcf = p.src + (long)frame * p.src_frame_pitch;
+    const int ycol = clampi16(gx0 - 4 + tid, 0, W - 1);
+    auto load_y = [&](int r) -> uint8_t {
+        const int rr = clampi16(r, 0, H - 1) - p.src_row0;
+        return srcf[(long)rr * p.src_stride + ycol];
+    };
+    const int c1col = tid == 0 ? SP_RS - 1 : tid - 1;                     // copy 1 holds column c at element c-1
+    auto stage_y = [&](int r, uint8_t v) {
+        const int slot = r & (YR - 1);
+        const _Float16 hv = (_Float16)((float)v * 6.103515625e-05f);
+        _Float16 *c0 = ring + slot * SP_RS + tid;
+        c0[0] = hv;
+        c0[YR * SP_RS] = hv;
+        _Float16 *c1 = ring + SP_CS + slot * SP_RS + c1col;
+        c1[0] = hv;
+        c1[YR * SP_RS] = hv;
+    };
+    {
+        uint8_t v[11];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) v[q] = load_y(f_lo - 4 + q);
+#pragma unroll
+        for (int q = 0; q < 11; ++q) stage_y(f_lo - 4 + q, v[q]);
+    }
+    __syncthreads();
+
+    const int xi = 32 * wave + j;
+    const int gx = gx0 + xi;
+    int xn[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) xn[n] = clampi16(clampi16(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+    const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+    float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    auto finalize = [&](int y, float acc, bool ok) {
+        const float v = __builtin_fmaf(acc, S16_UNSCALE_L3, p.b3);
+        const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
+        uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
+        *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
+        if constexpr (PRE) {
+            float *dp = ok ? p.pre + o : p.sink + 64 + lane;
+            *dp = v;
+        }
+    };
+    auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
+    auto vertical = [&](int f, const f32x16 &t) {
+        const int fplane = 3 * half * FW + xi;
+        if (f > 0) {
+            float *fo = ftile(f, 0) + fplane;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                fo[s * FW] = R[3][s] + t[5 * s + 4];
+                R[3][s] = R[2][s] + t[5 * s + 3];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[1][s] = R[0][s] + t[5 * s + 1];
+                R[0][s] = t[5 * s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                R[0][s] = t[5 * s];
+                R[1][s] = t[5 * s] + t[5 * s + 1];
+                R[2][s] = R[1][s] + t[5 * s + 2];
+                R[3][s] = 0.f;
+            }
+        }
+        if (f == H - 1) {
+            float *f1 = ftile(f, 1) + fplane, *f2 = ftile(f, 2) + fplane;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                f1[s * FW] = R[3][s] + t[5 * s + 4];
+                f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
+            }
+        }
+    };
+    float hv[5];
+    auto hp_load = [&](int g, int slot) {
+        const float *fr = ftile(g, slot);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) hv[n] = fr[n * FW + xn[n]];
+    };
+    auto hp_use = [&](int g, int slot, bool on) {
+        float acc = hv[0];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) acc += hv[n];
+        const int y = g - 2 + slot;
+        finalize(y, acc, on && px_ok && (y >= ys) && (y < ye));
+    };
+
+    const int ring_lane = (xi & 1) * SP_CS + (xi & ~1);
+    unsigned bq[24];
+    auto read_b = [&](int f) {
+        const unsigned *yb = reinterpret_cast<const unsigned *>(ring + ring_lane + ((f - 4) & (YR - 1)) * SP_RS);
+        const unsigned *ybH = yb + half * (5 * SP_RS / 2);
+        const unsigned *ybX = yb + 4 * (SP_RS / 2) + 2 * half;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) bq[rr * 5 + q] = ybH[rr * (SP_RS / 2) + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bq[20 + q] = ybX[q];
+        bq[23] = 0x00003C00u;
+    };
+#define BV(b) ((u32x4){bq[4 * (b)], bq[4 * (b) + 1], bq[4 * (b) + 2], bq[4 * (b) + 3]})
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+
+    // prologue: layer 1 of the first row, not overlapped
+    f32x16 accA0 = {0}, accA1 = {0}, accB0, accB1;
+    read_b(f_lo);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        accA0 = MFMA16(w1[0][0][b], BV(b), accA0);
+        accA1 = MFMA16(w1[1][0][b], BV(b), accA1);
+        accA0 = MFMA16(w1[0][1][b], BV(b), accA0);
+        accA1 = MFMA16(w1[1][1][b], BV(b), accA1);
+    }
+    PIN();
+    read_b(f_lo + 1);
+
+    // One row: consume (c0, c1) = layer-1 result of row f, produce (n0, n1) = layer 1 of row f+1.
+    auto row = [&](int f, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) {
+        const int g = f - 1;
+        const bool hp = g >= f_lo;
+        unsigned ynext = load_y(f + 7);
+        unsigned h1[16], l1[16], h2[8], l2[8];
+        f32x16 d2 = {0}, t = {0};
+        n0 = (f32x16){0};
+        n1 = (f32x16){0};
+        auto sp1 = [&](int q) {
+            if (q < 8) relu_split_pair(c0[2 * q], c0[2 * q + 1], h1[q], l1[q]);
+            else relu_split_pair(c1[2 * (q - 8)], c1[2 * (q - 8) + 1], h1[q], l1[q]);
+        };
+        auto sp2 = [&](int q) {
+            relu_split_pair(__builtin_fmaf(d2[2 * q], S16_UNSCALE_L2, b2v[2 * q]),
+                            __builtin_fmaf(d2[2 * q + 1], S16_UNSCALE_L2, b2v[2 * q + 1]), h2[q], l2[q]);
+        };
+        auto bh1 = [&](int b) -> u32x4 { return (u32x4){h1[4 * b], h1[4 * b + 1], h1[4 * b + 2], h1[4 * b + 3]}; };
+        auto bl1 = [&](int b) -> u32x4 { return (u32x4){l1[4 * b], l1[4 * b + 1], l1[4 * b + 2], l1[4 * b + 3]}; };
+        auto bh2 = [&](int b) -> u32x4 { return (u32x4){h2[4 * b], h2[4 * b + 1], h2[4 * b + 2], h2[4 * b + 3]}; };
+        auto bl2 = [&](int b) -> u32x4 { return (u32x4){l2[4 * b], l2[4 * b + 1], l2[4 * b + 2], l2[4 * b + 3]}; };
+        PIN();
+        //  1- 4: layer 1 (next row) k-block 0 | split pairs 0-3 of this row's layer-1 result
+        n0 = MFMA16(w1[0][0][0], BV(0), n0); sp1(0); PIN();
+        n1 = MFMA16(w1[1][0][0], BV(0), n1); sp1(1); PIN();
+        n0 = MFMA16(w1[0][1][0], BV(0), n0); sp1(2); PIN();
+        n1 = MFMA16(w1[1][1][0], BV(0), n1); sp1(3); PIN();
+        //  5-16: layer 2 k-blocks 0,1 alternating with layer 1 k-blocks 1,2 | split pairs 4-15
+        d2 = MFMA16(w2[0][0], bh1(0), d2); sp1(4); PIN();
+        n0 = MFMA16(w1[0][0][1], BV(1), n0); sp1(5); PIN();
+        d2 = MFMA16(w2[1][0], bh1(0), d2); sp1(6); PIN();
+        n1 = MFMA16(w1[1][0][1], BV(1), n1); sp1(7); PIN();
+        d2 = MFMA16(w2[0][0], bl1(0), d2); sp1(8); PIN();
+        n0 = MFMA16(w1[0][1][1], BV(1), n0); sp1(9); PIN();
+        d2 = MFMA16(w2[0][1], bh1(1), d2); sp1(10); PIN();
+        n1 = MFMA16(w1[1][1][1], BV(1), n1); sp1(11); PIN();
+        d2 = MFMA16(w2[1][1], bh1(1), d2); sp1(12); PIN();
+        n0 = MFMA16(w1[0][0][2], BV(2), n0); sp1(13); PIN();
+        d2 = MFMA16(w2[0][1], bl1(1), d2); sp1(14); PIN();
+        n1 = MFMA16(w1[1][0][2], BV(2), n1); sp1(15); PIN();
+        // 17-28: layer 2 k-blocks 2,3 alternating with layer 1 | horizontal sum of the previous row, Y staging
+        d2 = MFMA16(w2[0][2], bh1(2), d2); hp_load(g, 0); PIN();
+        n0 = MFMA16(w1[0][1][2], BV(2), n0); PIN();
+        d2 = MFMA16(w2[1][2], bh1(2), d2); PIN();
+        n1 = MFMA16(w1[1][1][2], BV(2), n1); hp_use(g, 0, hp); PIN();
+        d2 = MFMA16(w2[0][2], bl1(2), d2); PIN();
+        n0 = MFMA16(w1[0][0][3], BV(3), n0); PIN();
+        d2 = MFMA16(w2[0][3], bh1(3), d2); stage_y(f + 7, (uint8_t)ynext); PIN();
+        n1 = MFMA16(w1[1][0][3], BV(3), n1); PIN();
+        d2 = MFMA16(w2[1][3], bh1(3), d2); PIN();
+        n0 = MFMA16(w1[0][1][3], BV(3), n0); PIN();
+        d2 = MFMA16(w2[0][3], bl1(3), d2); PIN();
+        n1 = MFMA16(w1[1][1][3], BV(3), n1); PIN();
+        // 29-33: layer 1 k-blocks 4,5 | rescale + bias + split of the layer-2 result
+        n0 = MFMA16(w1[0][0][4], BV(4), n0); PIN();
+        n1 = MFMA16(w1[1][0][4], BV(4), n1); sp2(0); PIN();
+        n0 = MFMA16(w1[0][1][4], BV(4), n0); sp2(1); PIN();
+        n1 = MFMA16(w1[1][1][4], BV(4), n1); sp2(2); PIN();
+        n0 = MFMA16(w1[0][0][5], BV(5), n0); sp2(3); PIN();
+        // 34-42: layer 3 alternating with the last layer-1 MFMAs | remaining splits
+        t = MFMA16(w3[0][0], bh2(0), t); sp2(4); PIN();
+        n1 = MFMA16(w1[1][0][5], BV(5), n1); sp2(5); PIN();
+        t = MFMA16(w3[1][0], bh2(0), t); sp2(6); PIN();
+        n0 = MFMA16(w1[0][1][5], BV(5), n0); sp2(7); PIN();
+        t = MFMA16(w3[0][0], bl2(0), t); PIN();
+        n1 = MFMA16(w1[1][1][5], BV(5), n1); PIN();
+        // the B operands of this row are dead now: read those of row f+2 (rows up to f+6 are staged)
+        t = MFMA16(w3[0][1], bh2(1), t); read_b(f + 2); PIN();
+        t = MFMA16(w3[1][1], bh2(1), t); PIN();
+        t = MFMA16(w3[0][1], bl2(1), t); PIN();
+        vertical(f, t);
+        lds_barrier16();
+    };
+
+    int f = f_lo;
+    for (; f + 1 < f_hi; f += 2) {
+        row(f, accA0, accA1, accB0, accB1);
+        row(f + 1, accB0, accB1, accA0, accA1);
+    }
+    if (f < f_hi) {
+        row(f, accA0, accA1, accB0, accB1);
+        ++f;
+    }
+    // drain: the horizontal sums of the last feature row (f == f_hi here)
+    {
+        const int g = f - 1;
+        if (g >= f_lo) {
+            const int nslots = (g == H - 1) ? 3 : 1;
+            for (int slot = 0; slot < nslots; ++slot) {
+                hp_load(g, slot);
+                hp_use(g, slot, true);
+            }
+        }
+    }
+#undef BV
+#undef PIN
+}
+
 }  // namespace
 
 size_t split16_lds_bytes() { return (size_t)S16_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
+size_t split16p_lds_bytes() { return (size_t)SP_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
 
 hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
     const size_t lds = split16_lds_bytes() + lds_pad;
+    if (p.tune & 4) {       // experiment: software-pipelined variant, one workgroup per CU
+        const size_t ldsp = split16p_lds_bytes() + lds_pad;
+        if (p.pre) hipLaunchKernelGGL((srcnn_split16p_kernel<true>), grid, block, ldsp, stream, p);
+        else hipLaunchKernelGGL((srcnn_split16p_kernel<false>), grid, block, ldsp, stream, p);
+        return hipGetLastError();
+    }
     if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16_kernel<false, true>), grid, block, lds, stream, p);
     else if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((srcnn_split16_kernel<false>), grid, block, lds, stream, p);
