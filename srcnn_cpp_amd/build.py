@@ -22,7 +22,9 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno
 # multiply-then-add arithmetic: contraction to FMA must stay off there.
 UNITS = [
     ("srcnn_mfma.hip", []),
-    ("srcnn_split16.hip", []),
+    # MFMA results are consumed by vector instructions: keep them in architectural VGPRs (the 1-wave/SIMD
+    # variant pins its weight fragments to AGPRs instead)
+    ("srcnn_split16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("srcnn_exact.hip", ["-ffp-contract=off"]),
     ("srcnn_pipeline.hip", []),
     ("srcnn_api.cpp", ["-x", "hip"]),

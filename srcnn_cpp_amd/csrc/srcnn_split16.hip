@@ -370,7 +370,7 @@ constexpr int SP_RS = 264;                      // ring row pitch in halfs: ever
 constexpr int SP_CS = 2 * YR * SP_RS + 32;
 constexpr int SP_RING_BYTES = 2 * SP_CS * 2;
 
-template <bool PRE>
+template <bool PRE, bool DIAG = false>
 __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -538,116 +538,182 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
     };
 
     const int ring_lane = (xi & 1) * SP_CS + (xi & ~1);
-    unsigned bq[24];
-    auto read_b = [&](int f) {
+    // B operand of feature row f: 23 dwords (l1s_tap()); part 0..3 = window rows rr of the lane-half, part 4 = row 4
+    auto read_b_part = [&](int f, unsigned (&bq)[24], int part) {
         const unsigned *yb = reinterpret_cast<const unsigned *>(ring + ring_lane + ((f - 4) & (YR - 1)) * SP_RS);
-        const unsigned *ybH = yb + half * (5 * SP_RS / 2);
-        const unsigned *ybX = yb + 4 * (SP_RS / 2) + 2 * half;
+        if (part < 4) {
+            const unsigned *ybH = yb + half * (5 * SP_RS / 2) + part * (SP_RS / 2);
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+            for (int q = 0; q < 5; ++q) bq[part * 5 + q] = ybH[q];
+        } else {
+            const unsigned *ybX = yb + 4 * (SP_RS / 2) + 2 * half;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) bq[rr * 5 + q] = ybH[rr * (SP_RS / 2) + q];
+            for (int q = 0; q < 3; ++q) bq[20 + q] = ybX[q];
+            bq[23] = 0x00003C00u;
+        }
+    };
+    auto read_b = [&](int f, unsigned (&bq)[24]) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bq[20 + q] = ybX[q];
-        bq[23] = 0x00003C00u;
+        for (int part = 0; part < 5; ++part) read_b_part(f, bq, part);
     };
 #define BV(b) ((u32x4){bq[4 * (b)], bq[4 * (b) + 1], bq[4 * (b) + 2], bq[4 * (b) + 3]})
 #define PIN() __builtin_amdgcn_sched_barrier(0)
+    // ReLU + split of a QUAD (four pairs = the eight values of one k-block operand) in four steps of four
+    // INDEPENDENT instructions, one step per MFMA gap: four independent vector instructions hide completely
+    // behind a 32-cycle f16 MFMA, while a dependent one right behind its producer costs ~4-9 cycles
+    // (tools/f16_probe.hip: [cvt,cvt,max,max] 37.3, [mixlo,mixlo,mixhi,mixhi] 41.2, four of a kind 32.8 cycles
+    // per MFMA).  v_fma_mixhi_f16 merges into the register v_fma_mixlo_f16 wrote a whole gap earlier.
+    // `dep` is the accumulator of the MFMA issued just before the step: naming it as an (unused) input ties the
+    // step behind that MFMA in program order -- the compiler otherwise sinks an MFMA whose result is not
+    // needed yet below the following steps, leaving one gap overfull and the next one empty.
+    auto q_cvt = [&](const float *x, unsigned *h, const f32x16 &dep) {
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2 ; after %3" : "=v"(h[0]) : "v"(x[0]), "v"(x[1]), "v"(dep));
+#pragma unroll
+        for (int i = 1; i < 4; ++i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x[2 * i]), "v"(x[2 * i + 1]));
+    };
+    auto q_max = [&](unsigned *h, const f32x16 &dep) {
+        asm volatile("v_pk_max_f16 %0, %0, 0 ; after %1" : "+v"(h[0]) : "v"(dep));
+#pragma unroll
+        for (int i = 1; i < 4; ++i) asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(h[i]));
+    };
+    auto q_lo = [&](const float *x, const unsigned *h, unsigned *l, const f32x16 &dep) {
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp ; after %3"
+                     : "=v"(l[0]) : "v"(h[0]), "v"(x[0]), "v"(dep));
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(l[i]) : "v"(h[i]), "v"(x[2 * i]));
+    };
+    auto q_hi = [&](const float *x, const unsigned *h, unsigned *l, const f32x16 &dep) {
+        asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp ; after %3"
+                     : "+v"(l[0]) : "v"(h[0]), "v"(x[1]), "v"(dep));
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l[i]) : "v"(h[i]), "v"(x[2 * i + 1]));
+    };
+    auto after = [&](const f32x16 &dep) { asm volatile("; after %0" ::"v"(dep)); };
 
     // prologue: layer 1 of the first row, not overlapped
     f32x16 accA0 = {0}, accA1 = {0}, accB0, accB1;
-    read_b(f_lo);
+    unsigned bqA[24], bqB[24];
+    read_b(f_lo, bqA);
+    {
+        unsigned (&bq)[24] = bqA;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        accA0 = MFMA16(w1[0][0][b], BV(b), accA0);
-        accA1 = MFMA16(w1[1][0][b], BV(b), accA1);
-        accA0 = MFMA16(w1[0][1][b], BV(b), accA0);
-        accA1 = MFMA16(w1[1][1][b], BV(b), accA1);
+        for (int b = 0; b < 6; ++b) {
+            accA0 = MFMA16(w1[0][0][b], BV(b), accA0);
+            accA1 = MFMA16(w1[1][0][b], BV(b), accA1);
+            accA0 = MFMA16(w1[0][1][b], BV(b), accA0);
+            accA1 = MFMA16(w1[1][1][b], BV(b), accA1);
+        }
     }
     PIN();
-    read_b(f_lo + 1);
+    read_b(f_lo + 1, bqB);
 
-    // One row: consume (c0, c1) = layer-1 result of row f, produce (n0, n1) = layer 1 of row f+1.
-    auto row = [&](int f, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1) {
+    unsigned long long dgp[6] = {0, 0, 0, 0, 0, 0};
+    auto stampp = [&]() -> unsigned long long {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    // One row: consume (c0, c1) = layer-1 result of row f, produce (n0, n1) = layer 1 of row f+1 from the
+    // B operands bq (read during the previous row); read the B operands of row f+2 into bqn.
+    auto row = [&](int f, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, unsigned (&bq)[24], unsigned (&bqn)[24]) {
         const int g = f - 1;
         const bool hp = g >= f_lo;
         unsigned ynext = load_y(f + 7);
         unsigned h1[16], l1[16], h2[8], l2[8];
+        float x1[32], e[16];
         f32x16 d2 = {0}, t = {0};
         n0 = (f32x16){0};
         n1 = (f32x16){0};
-        auto sp1 = [&](int q) {
-            if (q < 8) relu_split_pair(c0[2 * q], c0[2 * q + 1], h1[q], l1[q]);
-            else relu_split_pair(c1[2 * (q - 8)], c1[2 * (q - 8) + 1], h1[q], l1[q]);
-        };
-        auto sp2 = [&](int q) {
-            relu_split_pair(__builtin_fmaf(d2[2 * q], S16_UNSCALE_L2, b2v[2 * q]),
-                            __builtin_fmaf(d2[2 * q + 1], S16_UNSCALE_L2, b2v[2 * q + 1]), h2[q], l2[q]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            x1[i] = c0[i];
+            x1[16 + i] = c1[i];
+        }
+        // rescale + bias of half a quad of the layer-2 result (4 fma)
+        auto s2e = [&](int i0) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) e[i] = __builtin_fmaf(d2[i], S16_UNSCALE_L2, b2v[i]);
         };
         auto bh1 = [&](int b) -> u32x4 { return (u32x4){h1[4 * b], h1[4 * b + 1], h1[4 * b + 2], h1[4 * b + 3]}; };
         auto bl1 = [&](int b) -> u32x4 { return (u32x4){l1[4 * b], l1[4 * b + 1], l1[4 * b + 2], l1[4 * b + 3]}; };
         auto bh2 = [&](int b) -> u32x4 { return (u32x4){h2[4 * b], h2[4 * b + 1], h2[4 * b + 2], h2[4 * b + 3]}; };
         auto bl2 = [&](int b) -> u32x4 { return (u32x4){l2[4 * b], l2[4 * b + 1], l2[4 * b + 2], l2[4 * b + 3]}; };
+        unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+        if constexpr (DIAG) q0 = stampp();
         PIN();
-        //  1- 4: layer 1 (next row) k-block 0 | split pairs 0-3 of this row's layer-1 result
-        n0 = MFMA16(w1[0][0][0], BV(0), n0); sp1(0); PIN();
-        n1 = MFMA16(w1[1][0][0], BV(0), n1); sp1(1); PIN();
-        n0 = MFMA16(w1[0][1][0], BV(0), n0); sp1(2); PIN();
-        n1 = MFMA16(w1[1][1][0], BV(0), n1); sp1(3); PIN();
-        //  5-16: layer 2 k-blocks 0,1 alternating with layer 1 k-blocks 1,2 | split pairs 4-15
-        d2 = MFMA16(w2[0][0], bh1(0), d2); sp1(4); PIN();
-        n0 = MFMA16(w1[0][0][1], BV(1), n0); sp1(5); PIN();
-        d2 = MFMA16(w2[1][0], bh1(0), d2); sp1(6); PIN();
-        n1 = MFMA16(w1[1][0][1], BV(1), n1); sp1(7); PIN();
-        d2 = MFMA16(w2[0][0], bl1(0), d2); sp1(8); PIN();
-        n0 = MFMA16(w1[0][1][1], BV(1), n0); sp1(9); PIN();
-        d2 = MFMA16(w2[0][1], bh1(1), d2); sp1(10); PIN();
-        n1 = MFMA16(w1[1][1][1], BV(1), n1); sp1(11); PIN();
-        d2 = MFMA16(w2[1][1], bh1(1), d2); sp1(12); PIN();
-        n0 = MFMA16(w1[0][0][2], BV(2), n0); sp1(13); PIN();
-        d2 = MFMA16(w2[0][1], bl1(1), d2); sp1(14); PIN();
-        n1 = MFMA16(w1[1][0][2], BV(2), n1); sp1(15); PIN();
-        // 17-28: layer 2 k-blocks 2,3 alternating with layer 1 | horizontal sum of the previous row, Y staging
-        d2 = MFMA16(w2[0][2], bh1(2), d2); hp_load(g, 0); PIN();
-        n0 = MFMA16(w1[0][1][2], BV(2), n0); PIN();
-        d2 = MFMA16(w2[1][2], bh1(2), d2); PIN();
-        n1 = MFMA16(w1[1][1][2], BV(2), n1); hp_use(g, 0, hp); PIN();
-        d2 = MFMA16(w2[0][2], bl1(2), d2); PIN();
-        n0 = MFMA16(w1[0][0][3], BV(3), n0); PIN();
-        d2 = MFMA16(w2[0][3], bh1(3), d2); stage_y(f + 7, (uint8_t)ynext); PIN();
-        n1 = MFMA16(w1[1][0][3], BV(3), n1); PIN();
-        d2 = MFMA16(w2[1][3], bh1(3), d2); PIN();
-        n0 = MFMA16(w1[0][1][3], BV(3), n0); PIN();
-        d2 = MFMA16(w2[0][3], bl1(3), d2); PIN();
-        n1 = MFMA16(w1[1][1][3], BV(3), n1); PIN();
-        // 29-33: layer 1 k-blocks 4,5 | rescale + bias + split of the layer-2 result
-        n0 = MFMA16(w1[0][0][4], BV(4), n0); PIN();
-        n1 = MFMA16(w1[1][0][4], BV(4), n1); sp2(0); PIN();
-        n0 = MFMA16(w1[0][1][4], BV(4), n0); sp2(1); PIN();
-        n1 = MFMA16(w1[1][1][4], BV(4), n1); sp2(2); PIN();
-        n0 = MFMA16(w1[0][0][5], BV(5), n0); sp2(3); PIN();
-        // 34-42: layer 3 alternating with the last layer-1 MFMAs | remaining splits
-        t = MFMA16(w3[0][0], bh2(0), t); sp2(4); PIN();
-        n1 = MFMA16(w1[1][0][5], BV(5), n1); sp2(5); PIN();
-        t = MFMA16(w3[1][0], bh2(0), t); sp2(6); PIN();
-        n0 = MFMA16(w1[0][1][5], BV(5), n0); sp2(7); PIN();
-        t = MFMA16(w3[0][0], bl2(0), t); PIN();
-        n1 = MFMA16(w1[1][1][5], BV(5), n1); PIN();
-        // the B operands of this row are dead now: read those of row f+2 (rows up to f+6 are staged)
-        t = MFMA16(w3[0][1], bh2(1), t); read_b(f + 2); PIN();
+        // g1-g4: layer 1 of the next row | quad 0 of this row's layer-1 result; F tile reads of the previous row
+        n0 = MFMA16(w1[0][0][0], BV(0), n0); q_cvt(x1, h1, n0); hp_load(g, 0); PIN();
+        n1 = MFMA16(w1[1][0][0], BV(0), n1); q_max(h1, n1); PIN();
+        n0 = MFMA16(w1[0][1][0], BV(0), n0); q_lo(x1, h1, l1, n0); PIN();
+        n1 = MFMA16(w1[1][1][0], BV(0), n1); q_hi(x1, h1, l1, n1); PIN();
+        // g5-g16: layer 2 k-blocks 0-2, a layer-1 MFMA after each | quads 1-3
+        d2 = MFMA16(w2[0][0], bh1(0), d2); q_cvt(x1 + 8, h1 + 4, d2); PIN();
+        d2 = MFMA16(w2[1][0], bh1(0), d2); q_max(h1 + 4, d2); PIN();
+        d2 = MFMA16(w2[0][0], bl1(0), d2); q_lo(x1 + 8, h1 + 4, l1 + 4, d2); PIN();
+        n0 = MFMA16(w1[0][0][1], BV(1), n0); q_hi(x1 + 8, h1 + 4, l1 + 4, n0); PIN();
+        d2 = MFMA16(w2[0][1], bh1(1), d2); q_cvt(x1 + 16, h1 + 8, d2); PIN();
+        d2 = MFMA16(w2[1][1], bh1(1), d2); q_max(h1 + 8, d2); PIN();
+        d2 = MFMA16(w2[0][1], bl1(1), d2); q_lo(x1 + 16, h1 + 8, l1 + 8, d2); PIN();
+        n1 = MFMA16(w1[1][0][1], BV(1), n1); q_hi(x1 + 16, h1 + 8, l1 + 8, n1); PIN();
+        d2 = MFMA16(w2[0][2], bh1(2), d2); q_cvt(x1 + 24, h1 + 12, d2); PIN();
+        d2 = MFMA16(w2[1][2], bh1(2), d2); q_max(h1 + 12, d2); PIN();
+        d2 = MFMA16(w2[0][2], bl1(2), d2); q_lo(x1 + 24, h1 + 12, l1 + 12, d2); PIN();
+        n0 = MFMA16(w1[0][1][1], BV(1), n0); q_hi(x1 + 24, h1 + 12, l1 + 12, n0); PIN();
+        if constexpr (DIAG) { q1 = stampp(); PIN(); }
+        // g17-g22: last layer-2 k-block, then layer 1 | Y staging, B operands of row f+2, output of the previous row
+        d2 = MFMA16(w2[0][3], bh1(3), d2); after(d2); read_b_part(f + 2, bqn, 0); PIN();
+        d2 = MFMA16(w2[1][3], bh1(3), d2); after(d2); read_b_part(f + 2, bqn, 1); PIN();
+        d2 = MFMA16(w2[0][3], bl1(3), d2); after(d2); read_b_part(f + 2, bqn, 2); PIN();
+        n1 = MFMA16(w1[1][1][1], BV(1), n1); after(n1); read_b_part(f + 2, bqn, 3); read_b_part(f + 2, bqn, 4); PIN();
+        n0 = MFMA16(w1[0][0][2], BV(2), n0); after(n0); stage_y(f + 7, (uint8_t)ynext); PIN();
+        n1 = MFMA16(w1[1][0][2], BV(2), n1); after(n1); hp_use(g, 0, hp); PIN();
+        if constexpr (DIAG) { q2 = stampp(); PIN(); }
+        // g23-g34: layer 1, layer 3 k-block 0 | rescale + bias, ReLU + split of the layer-2 result (two quads)
+        n0 = MFMA16(w1[0][1][2], BV(2), n0); after(n0); s2e(0); PIN();
+        n1 = MFMA16(w1[1][1][2], BV(2), n1); after(n1); s2e(4); PIN();
+        n0 = MFMA16(w1[0][0][3], BV(3), n0); q_cvt(e, h2, n0); PIN();
+        n1 = MFMA16(w1[1][0][3], BV(3), n1); q_max(h2, n1); PIN();
+        n0 = MFMA16(w1[0][1][3], BV(3), n0); q_lo(e, h2, l2, n0); PIN();
+        n1 = MFMA16(w1[1][1][3], BV(3), n1); q_hi(e, h2, l2, n1); PIN();
+        t = MFMA16(w3[0][0], bh2(0), t); after(t); s2e(8); PIN();
+        t = MFMA16(w3[1][0], bh2(0), t); after(t); s2e(12); PIN();
+        t = MFMA16(w3[0][0], bl2(0), t); q_cvt(e + 8, h2 + 4, t); PIN();
+        n0 = MFMA16(w1[0][0][4], BV(4), n0); q_max(h2 + 4, n0); PIN();
+        n1 = MFMA16(w1[1][0][4], BV(4), n1); q_lo(e + 8, h2 + 4, l2 + 4, n1); PIN();
+        n0 = MFMA16(w1[0][1][4], BV(4), n0); q_hi(e + 8, h2 + 4, l2 + 4, n0); PIN();
+        if constexpr (DIAG) { q3 = stampp(); PIN(); }
+        // g35-g42: layer 3 k-block 1, the last layer-1 MFMAs behind it so that t is complete at the end
+        t = MFMA16(w3[0][1], bh2(1), t); PIN();
         t = MFMA16(w3[1][1], bh2(1), t); PIN();
         t = MFMA16(w3[0][1], bl2(1), t); PIN();
+        n1 = MFMA16(w1[1][1][4], BV(4), n1); PIN();
+        n0 = MFMA16(w1[0][0][5], BV(5), n0); PIN();
+        n1 = MFMA16(w1[1][0][5], BV(5), n1); PIN();
+        n0 = MFMA16(w1[0][1][5], BV(5), n0); PIN();
+        n1 = MFMA16(w1[1][1][5], BV(5), n1); PIN();
+        if constexpr (DIAG) { q4 = stampp(); PIN(); }
         vertical(f, t);
         lds_barrier16();
+        if constexpr (DIAG) {
+            q5 = stampp();
+            dgp[0] += q1 - q0; dgp[1] += q2 - q1; dgp[2] += q3 - q2; dgp[3] += q4 - q3; dgp[4] += q5 - q4;
+        }
     };
 
+    unsigned long long dg_t0 = 0, dg_r0 = 0;
+    if constexpr (DIAG) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t0)::"memory");
+        dg_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     int f = f_lo;
     for (; f + 1 < f_hi; f += 2) {
-        row(f, accA0, accA1, accB0, accB1);
-        row(f + 1, accB0, accB1, accA0, accA1);
+        row(f, accA0, accA1, accB0, accB1, bqB, bqA);
+        row(f + 1, accB0, accB1, accA0, accA1, bqA, bqB);
     }
     if (f < f_hi) {
-        row(f, accA0, accA1, accB0, accB1);
+        row(f, accA0, accA1, accB0, accB1, bqB, bqA);
         ++f;
     }
     // drain: the horizontal sums of the last feature row (f == f_hi here)
@@ -659,6 +725,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
                 hp_load(g, slot);
                 hp_use(g, slot, true);
             }
+        }
+    }
+    if constexpr (DIAG) {
+        unsigned long long t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) + ((long)blockIdx.x * NWAVES + wave) * 8;
+            o[0] = t1 - dg_t0;
+            o[1] = r1 - dg_r0;
+            o[2] = dgp[0]; o[3] = dgp[1]; o[4] = dgp[2]; o[5] = dgp[3];
+            o[6] = (unsigned long long)(f_hi - f_lo) | ((dg_r0 & 0xffffffffull) << 32);
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (dgp[4] << 32);
         }
     }
 #undef BV
@@ -677,7 +756,8 @@ hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream
     const size_t lds = split16_lds_bytes() + lds_pad;
     if (p.tune & 4) {       // experiment: software-pipelined variant, one workgroup per CU
         const size_t ldsp = split16p_lds_bytes() + lds_pad;
-        if (p.pre) hipLaunchKernelGGL((srcnn_split16p_kernel<true>), grid, block, ldsp, stream, p);
+        if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16p_kernel<false, true>), grid, block, ldsp, stream, p);
+        else if (p.pre) hipLaunchKernelGGL((srcnn_split16p_kernel<true>), grid, block, ldsp, stream, p);
         else hipLaunchKernelGGL((srcnn_split16p_kernel<false>), grid, block, ldsp, stream, p);
         return hipGetLastError();
     }

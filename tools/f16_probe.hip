@@ -60,6 +60,45 @@ __device__ __forceinline__ void body(int iters, float &sink, u32x4 wa, u32x4 wb)
                                "v_fma_mixlo_f16 %4, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %5, %1, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
                                "v_fma_mixhi_f16 %4, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %5, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                                : "=&v"(u0), "=&v"(u1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));)
+        } else if constexpr (ROLE >= 11 && ROLE <= 19) {   // MFMA + the split instructions of srcnn_split16.hip per gap
+            unsigned h0 = 0, h1 = 0, l0 = 0, l1 = 0;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                c = MFMA16(wa, wb, c);
+                if constexpr (ROLE == 11) {        // cvt, cvt, pk_max, pk_max
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\tv_cvt_pkrtz_f16_f32 %1, %4, %5\n\tv_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0"
+                                 : "=&v"(h0), "=&v"(h1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+                    u0 ^= h0; u1 ^= h1;
+                } else if constexpr (ROLE == 12) { // mixlo, mixlo, mixhi, mixhi
+                    asm volatile("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0] clamp\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel_hi:[1,0,0] clamp\n\t"
+                                 "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\tv_fma_mixhi_f16 %1, %3, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp"
+                                 : "+v"(l0), "+v"(l1) : "v"(u0), "v"(u1), "v"(x0), "v"(x1));
+                } else if constexpr (ROLE == 13) { // cvt, cvt only
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\tv_cvt_pkrtz_f16_f32 %1, %4, %5" : "=&v"(h0), "=&v"(h1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+                    u0 ^= h0; u1 ^= h1;
+                } else if constexpr (ROLE == 14) { // four cvt
+                    asm volatile("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\tv_cvt_pkrtz_f16_f32 %1, %4, %5\n\tv_cvt_pkrtz_f16_f32 %0, %3, %2\n\tv_cvt_pkrtz_f16_f32 %1, %5, %4" : "=&v"(h0), "=&v"(h1) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+                } else if constexpr (ROLE == 15) { // four pk_max
+                    asm volatile("v_pk_max_f16 %0, %0, 0\n\tv_pk_max_f16 %1, %1, 0\n\tv_pk_max_f16 %2, %2, 0\n\tv_pk_max_f16 %3, %3, 0" : "+v"(u0), "+v"(u1), "+v"(l0), "+v"(l1));
+                } else if constexpr (ROLE == 17) { // four independent mixlo
+                    asm volatile("v_fma_mixlo_f16 %0, %4, -1.0, %6 op_sel_hi:[1,0,0] clamp\n\tv_fma_mixlo_f16 %1, %5, -1.0, %7 op_sel_hi:[1,0,0] clamp\n\t"
+                                 "v_fma_mixlo_f16 %2, %4, -1.0, %7 op_sel_hi:[1,0,0] clamp\n\tv_fma_mixlo_f16 %3, %5, -1.0, %6 op_sel_hi:[1,0,0] clamp"
+                                 : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1) : "v"(u0), "v"(u1), "v"(x0), "v"(x1));
+                } else if constexpr (ROLE == 18) { // four independent mixhi
+                    asm volatile("v_fma_mixhi_f16 %0, %4, -1.0, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\tv_fma_mixhi_f16 %1, %5, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\t"
+                                 "v_fma_mixhi_f16 %2, %4, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp\n\tv_fma_mixhi_f16 %3, %5, -1.0, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp"
+                                 : "+v"(l0), "+v"(l1), "+v"(h0), "+v"(h1) : "v"(u0), "v"(u1), "v"(x0), "v"(x1));
+                } else if constexpr (ROLE == 19) { // four fma_f32 (the rescale + bias step)
+                    asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(sink), "v"(sink));
+                } else {                           // three mix instructions
+                    asm volatile("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel_hi:[1,0,0] clamp\n\tv_fma_mixlo_f16 %1, %3, -1.0, %5 op_sel_hi:[1,0,0] clamp\n\t"
+                                 "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp"
+                                 : "+v"(l0), "+v"(l1) : "v"(u0), "v"(u1), "v"(x0), "v"(x1));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            u0 ^= l0; u1 ^= l1;
         } else if constexpr (ROLE == 8) {      // MFMA whose result is read by a vector instruction at once
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -134,6 +173,15 @@ int main()
     run<7, 6, 0>("MFMA + 6 fillers per gap", 256, 64, 1);
     run<7, 8, 0>("MFMA + 8 fillers per gap", 256, 64, 1);
     run<7, 12, 0>("MFMA + 12 fillers per gap", 256, 64, 1);
+    run<11, 0, 0>("MFMA + [cvt_pkrtz x2, pk_max x2] per gap", 256, 64, 1);
+    run<12, 0, 0>("MFMA + [fma_mixlo x2, fma_mixhi x2] per gap", 256, 64, 1);
+    run<13, 0, 0>("MFMA + [cvt_pkrtz x2] per gap", 256, 64, 1);
+    run<14, 0, 0>("MFMA + [cvt_pkrtz x4] per gap", 256, 64, 1);
+    run<15, 0, 0>("MFMA + [pk_max x4] per gap", 256, 64, 1);
+    run<16, 0, 0>("MFMA + [fma_mix x3] per gap", 256, 64, 1);
+    run<17, 0, 0>("MFMA + [fma_mixlo x4, independent] per gap", 256, 64, 1);
+    run<18, 0, 0>("MFMA + [fma_mixhi x4, independent] per gap", 256, 64, 1);
+    run<19, 0, 0>("MFMA + [v_fma_f32 x4] per gap", 256, 64, 1);
     run<8, 0, 0>("MFMA -> v_max of its result -> next MFMA (per MFMA)", 256, 16, 1);
     run<0, 0, 0>("2 waves/SIMD: A = MFMA chain, B = MFMA chain", 512, 64, 64);
     run<0, 0, 1>("2 waves/SIMD: A = MFMA chain, B = v_max stream", 512, 64, 128);
