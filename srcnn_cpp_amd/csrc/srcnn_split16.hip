@@ -558,37 +558,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
     };
 #define BV(b) ((u32x4){bq[4 * (b)], bq[4 * (b) + 1], bq[4 * (b) + 2], bq[4 * (b) + 3]})
 #define PIN() __builtin_amdgcn_sched_barrier(0)
-    // ReLU + split of a QUAD (four pairs = the eight values of one k-block operand) in four steps of four
-    // INDEPENDENT instructions, one step per MFMA gap: four independent vector instructions hide completely
-    // behind a 32-cycle f16 MFMA, while a dependent one right behind its producer costs ~4-9 cycles
-    // (tools/f16_probe.hip: [cvt,cvt,max,max] 37.3, [mixlo,mixlo,mixhi,mixhi] 41.2, four of a kind 32.8 cycles
-    // per MFMA).  v_fma_mixhi_f16 merges into the register v_fma_mixlo_f16 wrote a whole gap earlier.
-    // `dep` is the accumulator of the MFMA issued just before the step: naming it as an (unused) input ties the
-    // step behind that MFMA in program order -- the compiler otherwise sinks an MFMA whose result is not
-    // needed yet below the following steps, leaving one gap overfull and the next one empty.
-    auto q_cvt = [&](const float *x, unsigned *h, const f32x16 &dep) {
+    // ReLU + split steps on TWO pairs (four values x[0..3] -> h[0..1], l[0..1]).  Costs inside the shadow of a
+    // 32-cycle f16 MFMA (tools/f16_probe.hip): v_cvt_pkrtz / v_pk_max / v_fma_f32 4 cycles, v_fma_mixlo/hi_f16 8;
+    // the MFMA itself holds the issue port 8 cycles, so a gap hides 24 cycles of INDEPENDENT vector work: two mix
+    // plus two simple instructions, or four simple ones.  A dependent instruction right behind its producer
+    // stalls, so every step works on values produced at least one gap earlier.  `dep` is the accumulator of the
+    // MFMA issued just before the step: naming it as an (unused) input ties the step behind that MFMA in
+    // program order -- the compiler otherwise sinks an MFMA whose result is not needed yet below the
+    // following steps, leaving one gap overfull and the next one empty.
+    auto cvt2 = [&](const float *x, unsigned *h, const f32x16 &dep) {
         asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2 ; after %3" : "=v"(h[0]) : "v"(x[0]), "v"(x[1]), "v"(dep));
-#pragma unroll
-        for (int i = 1; i < 4; ++i) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(h[i]) : "v"(x[2 * i]), "v"(x[2 * i + 1]));
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(h[1]) : "v"(x[2]), "v"(x[3]));
     };
-    auto q_max = [&](unsigned *h, const f32x16 &dep) {
+    auto max2 = [&](unsigned *h, const f32x16 &dep) {
         asm volatile("v_pk_max_f16 %0, %0, 0 ; after %1" : "+v"(h[0]) : "v"(dep));
-#pragma unroll
-        for (int i = 1; i < 4; ++i) asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(h[i]));
+        asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(h[1]));
     };
-    auto q_lo = [&](const float *x, const unsigned *h, unsigned *l, const f32x16 &dep) {
-        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp ; after %3"
-                     : "=v"(l[0]) : "v"(h[0]), "v"(x[0]), "v"(dep));
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-            asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(l[i]) : "v"(h[i]), "v"(x[2 * i]));
+    auto lo2 = [&](const float *x, const unsigned *h, unsigned *l) {
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(l[0]) : "v"(h[0]), "v"(x[0]));
+        asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(l[1]) : "v"(h[1]), "v"(x[2]));
     };
-    auto q_hi = [&](const float *x, const unsigned *h, unsigned *l, const f32x16 &dep) {
-        asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp ; after %3"
-                     : "+v"(l[0]) : "v"(h[0]), "v"(x[1]), "v"(dep));
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-            asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l[i]) : "v"(h[i]), "v"(x[2 * i + 1]));
+    auto hi2 = [&](const float *x, const unsigned *h, unsigned *l) {
+        asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l[0]) : "v"(h[0]), "v"(x[1]));
+        asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(l[1]) : "v"(h[1]), "v"(x[3]));
     };
     auto after = [&](const f32x16 &dep) { asm volatile("; after %0" ::"v"(dep)); };
 
@@ -643,56 +635,90 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
         unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
         if constexpr (DIAG) q0 = stampp();
         PIN();
-        // g1-g4: layer 1 of the next row | quad 0 of this row's layer-1 result; F tile reads of the previous row
-        n0 = MFMA16(w1[0][0][0], BV(0), n0); q_cvt(x1, h1, n0); hp_load(g, 0); PIN();
-        n1 = MFMA16(w1[1][0][0], BV(0), n1); q_max(h1, n1); PIN();
-        n0 = MFMA16(w1[0][1][0], BV(0), n0); q_lo(x1, h1, l1, n0); PIN();
-        n1 = MFMA16(w1[1][1][0], BV(0), n1); q_hi(x1, h1, l1, n1); PIN();
-        // g5-g16: layer 2 k-blocks 0-2, a layer-1 MFMA after each | quads 1-3
-        d2 = MFMA16(w2[0][0], bh1(0), d2); q_cvt(x1 + 8, h1 + 4, d2); PIN();
-        d2 = MFMA16(w2[1][0], bh1(0), d2); q_max(h1 + 4, d2); PIN();
-        d2 = MFMA16(w2[0][0], bl1(0), d2); q_lo(x1 + 8, h1 + 4, l1 + 4, d2); PIN();
-        n0 = MFMA16(w1[0][0][1], BV(1), n0); q_hi(x1 + 8, h1 + 4, l1 + 4, n0); PIN();
-        d2 = MFMA16(w2[0][1], bh1(1), d2); q_cvt(x1 + 16, h1 + 8, d2); PIN();
-        d2 = MFMA16(w2[1][1], bh1(1), d2); q_max(h1 + 8, d2); PIN();
-        d2 = MFMA16(w2[0][1], bl1(1), d2); q_lo(x1 + 16, h1 + 8, l1 + 8, d2); PIN();
-        n1 = MFMA16(w1[1][0][1], BV(1), n1); q_hi(x1 + 16, h1 + 8, l1 + 8, n1); PIN();
-        d2 = MFMA16(w2[0][2], bh1(2), d2); q_cvt(x1 + 24, h1 + 12, d2); PIN();
-        d2 = MFMA16(w2[1][2], bh1(2), d2); q_max(h1 + 12, d2); PIN();
-        d2 = MFMA16(w2[0][2], bl1(2), d2); q_lo(x1 + 24, h1 + 12, l1 + 12, d2); PIN();
-        n0 = MFMA16(w1[0][1][1], BV(1), n0); q_hi(x1 + 24, h1 + 12, l1 + 12, n0); PIN();
+        // Values are converted in QUADS (4 pairs = the 8 values of one k-block operand).  In every gap the two
+        // simple steps of quad q (cvt or max of two pairs) share the gap with two mix instructions of quad q-1:
+        //   SIMPLE(q, j):  j = 0,1: cvt of pairs 0-1 / 2-3;  j = 2,3: max of pairs 0-1 / 2-3
+        //   MIX(q, j):     j = 0,1: mixlo of pairs 0-1 / 2-3;  j = 2,3: mixhi of pairs 0-1 / 2-3
+        // so the hi part of quad q is complete 4 gaps after its first step, the lo part 8 gaps after.
+#define SIMPLE1(q, j, dep)                                                                         \
+    do {                                                                                           \
+        if ((j) < 2) cvt2(x1 + 8 * (q) + 4 * (j), h1 + 4 * (q) + 2 * (j), dep);                    \
+        else max2(h1 + 4 * (q) + 2 * ((j) - 2), dep);                                              \
+    } while (0)
+#define MIX1(q, j)                                                                                 \
+    do {                                                                                           \
+        if ((j) < 2) lo2(x1 + 8 * (q) + 4 * (j), h1 + 4 * (q) + 2 * (j), l1 + 4 * (q) + 2 * (j));  \
+        else hi2(x1 + 8 * (q) + 4 * ((j) - 2), h1 + 4 * (q) + 2 * ((j) - 2), l1 + 4 * (q) + 2 * ((j) - 2)); \
+    } while (0)
+#define SIMPLE2(q, j, dep)                                                                         \
+    do {                                                                                           \
+        if ((j) < 2) cvt2(e + 8 * (q) + 4 * (j), h2 + 4 * (q) + 2 * (j), dep);                     \
+        else max2(h2 + 4 * (q) + 2 * ((j) - 2), dep);                                              \
+    } while (0)
+#define MIX2(q, j)                                                                                 \
+    do {                                                                                           \
+        if ((j) < 2) lo2(e + 8 * (q) + 4 * (j), h2 + 4 * (q) + 2 * (j), l2 + 4 * (q) + 2 * (j));   \
+        else hi2(e + 8 * (q) + 4 * ((j) - 2), h2 + 4 * (q) + 2 * ((j) - 2), l2 + 4 * (q) + 2 * ((j) - 2)); \
+    } while (0)
+        // g1-g4: layer 1 of the next row | simple steps of quad 0; F tile reads of the previous row
+        n0 = MFMA16(w1[0][0][0], BV(0), n0); SIMPLE1(0, 0, n0); hp_load(g, 0); PIN();
+        n1 = MFMA16(w1[1][0][0], BV(0), n1); SIMPLE1(0, 1, n1); PIN();
+        n0 = MFMA16(w1[0][1][0], BV(0), n0); SIMPLE1(0, 2, n0); PIN();
+        n1 = MFMA16(w1[1][1][0], BV(0), n1); SIMPLE1(0, 3, n1); PIN();
+        // g5-g8: layer 2 k-block 0 (hi operand) | simple quad 1, mix quad 0
+        d2 = MFMA16(w2[0][0], bh1(0), d2); SIMPLE1(1, 0, d2); MIX1(0, 0); PIN();
+        d2 = MFMA16(w2[1][0], bh1(0), d2); SIMPLE1(1, 1, d2); MIX1(0, 1); PIN();
+        n0 = MFMA16(w1[0][0][1], BV(1), n0); SIMPLE1(1, 2, n0); MIX1(0, 2); PIN();
+        n1 = MFMA16(w1[1][0][1], BV(1), n1); SIMPLE1(1, 3, n1); MIX1(0, 3); PIN();
+        // g9-g12 | simple quad 2, mix quad 1
+        d2 = MFMA16(w2[0][0], bl1(0), d2); SIMPLE1(2, 0, d2); MIX1(1, 0); PIN();
+        d2 = MFMA16(w2[0][1], bh1(1), d2); SIMPLE1(2, 1, d2); MIX1(1, 1); PIN();
+        d2 = MFMA16(w2[1][1], bh1(1), d2); SIMPLE1(2, 2, d2); MIX1(1, 2); PIN();
+        n0 = MFMA16(w1[0][1][1], BV(1), n0); SIMPLE1(2, 3, n0); MIX1(1, 3); PIN();
+        // g13-g16 | simple quad 3, mix quad 2
+        d2 = MFMA16(w2[0][1], bl1(1), d2); SIMPLE1(3, 0, d2); MIX1(2, 0); PIN();
+        d2 = MFMA16(w2[0][2], bh1(2), d2); SIMPLE1(3, 1, d2); MIX1(2, 1); PIN();
+        d2 = MFMA16(w2[1][2], bh1(2), d2); SIMPLE1(3, 2, d2); MIX1(2, 2); PIN();
+        n1 = MFMA16(w1[1][1][1], BV(1), n1); SIMPLE1(3, 3, n1); MIX1(2, 3); PIN();
         if constexpr (DIAG) { q1 = stampp(); PIN(); }
-        // g17-g22: last layer-2 k-block, then layer 1 | Y staging, B operands of row f+2, output of the previous row
-        d2 = MFMA16(w2[0][3], bh1(3), d2); after(d2); read_b_part(f + 2, bqn, 0); PIN();
-        d2 = MFMA16(w2[1][3], bh1(3), d2); after(d2); read_b_part(f + 2, bqn, 1); PIN();
-        d2 = MFMA16(w2[0][3], bl1(3), d2); after(d2); read_b_part(f + 2, bqn, 2); PIN();
-        n1 = MFMA16(w1[1][1][1], BV(1), n1); after(n1); read_b_part(f + 2, bqn, 3); read_b_part(f + 2, bqn, 4); PIN();
-        n0 = MFMA16(w1[0][0][2], BV(2), n0); after(n0); stage_y(f + 7, (uint8_t)ynext); PIN();
-        n1 = MFMA16(w1[1][0][2], BV(2), n1); after(n1); hp_use(g, 0, hp); PIN();
+        // g17-g21 | mix quad 3; B operands of row f+2 (rows up to f+6 are staged and published)
+        d2 = MFMA16(w2[0][2], bl1(2), d2); after(d2); MIX1(3, 0); read_b_part(f + 2, bqn, 0); PIN();
+        d2 = MFMA16(w2[0][3], bh1(3), d2); after(d2); MIX1(3, 1); read_b_part(f + 2, bqn, 1); PIN();
+        d2 = MFMA16(w2[1][3], bh1(3), d2); after(d2); MIX1(3, 2); read_b_part(f + 2, bqn, 2); PIN();
+        n0 = MFMA16(w1[0][0][2], BV(2), n0); after(n0); MIX1(3, 3); read_b_part(f + 2, bqn, 3); PIN();
+        d2 = MFMA16(w2[0][3], bl1(3), d2); after(d2); read_b_part(f + 2, bqn, 4); PIN();
+        // g22-g23: layer 1 while the layer-2 result completes | Y staging, output of the previous row
+        n1 = MFMA16(w1[1][0][2], BV(2), n1); after(n1); stage_y(f + 7, (uint8_t)ynext); PIN();
+        n0 = MFMA16(w1[0][1][2], BV(2), n0); after(n0); hp_use(g, 0, hp); PIN();
         if constexpr (DIAG) { q2 = stampp(); PIN(); }
-        // g23-g34: layer 1, layer 3 k-block 0 | rescale + bias, ReLU + split of the layer-2 result (two quads)
-        n0 = MFMA16(w1[0][1][2], BV(2), n0); after(n0); s2e(0); PIN();
-        n1 = MFMA16(w1[1][1][2], BV(2), n1); after(n1); s2e(4); PIN();
-        n0 = MFMA16(w1[0][0][3], BV(3), n0); q_cvt(e, h2, n0); PIN();
-        n1 = MFMA16(w1[1][0][3], BV(3), n1); q_max(h2, n1); PIN();
-        n0 = MFMA16(w1[0][1][3], BV(3), n0); q_lo(e, h2, l2, n0); PIN();
-        n1 = MFMA16(w1[1][1][3], BV(3), n1); q_hi(e, h2, l2, n1); PIN();
-        t = MFMA16(w3[0][0], bh2(0), t); after(t); s2e(8); PIN();
-        t = MFMA16(w3[1][0], bh2(0), t); after(t); s2e(12); PIN();
-        t = MFMA16(w3[0][0], bl2(0), t); q_cvt(e + 8, h2 + 4, t); PIN();
-        n0 = MFMA16(w1[0][0][4], BV(4), n0); q_max(h2 + 4, n0); PIN();
-        n1 = MFMA16(w1[1][0][4], BV(4), n1); q_lo(e + 8, h2 + 4, l2 + 4, n1); PIN();
-        n0 = MFMA16(w1[0][1][4], BV(4), n0); q_hi(e + 8, h2 + 4, l2 + 4, n0); PIN();
+        // g24-g29: layer 1 | rescale + bias of the layer-2 result, simple steps of its quad 0
+        n1 = MFMA16(w1[1][1][2], BV(2), n1); after(n1); s2e(0); PIN();
+        n0 = MFMA16(w1[0][0][3], BV(3), n0); after(n0); s2e(4); PIN();
+        n1 = MFMA16(w1[1][0][3], BV(3), n1); SIMPLE2(0, 0, n1); s2e(8); PIN();
+        n0 = MFMA16(w1[0][1][3], BV(3), n0); SIMPLE2(0, 1, n0); s2e(12); PIN();
+        n1 = MFMA16(w1[1][1][3], BV(3), n1); SIMPLE2(0, 2, n1); PIN();
+        n0 = MFMA16(w1[0][0][4], BV(4), n0); SIMPLE2(0, 3, n0); PIN();
+        // g30-g33: layer 3 k-block 0 (hi operand) | simple quad 1, mix quad 0
+        t = MFMA16(w3[0][0], bh2(0), t); SIMPLE2(1, 0, t); MIX2(0, 0); PIN();
+        t = MFMA16(w3[1][0], bh2(0), t); SIMPLE2(1, 1, t); MIX2(0, 1); PIN();
+        n1 = MFMA16(w1[1][0][4], BV(4), n1); SIMPLE2(1, 2, n1); MIX2(0, 2); PIN();
+        n0 = MFMA16(w1[0][1][4], BV(4), n0); SIMPLE2(1, 3, n0); MIX2(0, 3); PIN();
+        // g34-g38 | mix quad 1
+        t = MFMA16(w3[0][0], bl2(0), t); after(t); MIX2(1, 0); PIN();
+        t = MFMA16(w3[0][1], bh2(1), t); after(t); MIX2(1, 1); PIN();
+        t = MFMA16(w3[1][1], bh2(1), t); after(t); MIX2(1, 2); PIN();
+        n1 = MFMA16(w1[1][1][4], BV(4), n1); after(n1); MIX2(1, 3); PIN();
+        t = MFMA16(w3[0][1], bl2(1), t); after(t); PIN();
         if constexpr (DIAG) { q3 = stampp(); PIN(); }
-        // g35-g42: layer 3 k-block 1, the last layer-1 MFMAs behind it so that t is complete at the end
-        t = MFMA16(w3[0][1], bh2(1), t); PIN();
-        t = MFMA16(w3[1][1], bh2(1), t); PIN();
-        t = MFMA16(w3[0][1], bl2(1), t); PIN();
-        n1 = MFMA16(w1[1][1][4], BV(4), n1); PIN();
+        // g39-g42: the last layer-1 MFMAs; t is complete when they are through
         n0 = MFMA16(w1[0][0][5], BV(5), n0); PIN();
         n1 = MFMA16(w1[1][0][5], BV(5), n1); PIN();
         n0 = MFMA16(w1[0][1][5], BV(5), n0); PIN();
         n1 = MFMA16(w1[1][1][5], BV(5), n1); PIN();
+#undef SIMPLE1
+#undef MIX1
+#undef SIMPLE2
+#undef MIX2
         if constexpr (DIAG) { q4 = stampp(); PIN(); }
         vertical(f, t);
         lds_barrier16();
