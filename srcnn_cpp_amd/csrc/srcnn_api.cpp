@@ -51,7 +51,7 @@ struct srcnn_ctx {
     // second lane of the host-frame pipeline (srcnn_forward_y_frames)
     // explicit work items of single-round launches (build_items), cached per geometry
     DevBuf items;
-    int items_key[5] = {0, 0, 0, 0, 0};
+    int items_key[6] = {0, 0, 0, 0, 0, 0};
     int items_count = 0;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     DevBuf lane_in[2], lane_out[2];
@@ -255,11 +255,11 @@ struct Plan {
 // rows per segment) and fewer workgroup start-ups (weight fragments, 9-row Y prologue: worth about
 // STARTUP_ROWS rows), more segments fill the 2-workgroups-per-CU slots more evenly.  Everything is
 // regular, so scan.
-Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo)
+Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, int wgs_per_cu = 2)
 {
     const int ow = FW - 2 * halo;
     Plan best{rows, (width + ow - 1) / ow, 1};
-    const long slots = 2L * c->n_cu;
+    const long slots = (long)wgs_per_cu * c->n_cu;
     double best_eff = -1.0;
     const int max_segs = std::min(rows, 4096);
     for (int ns = 1; ns <= max_segs; ++ns) {
@@ -289,21 +289,23 @@ bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0
 // 2*n_cu items are made: every strip is cut into k or k+1 segments, the "fast" ones (first n_cu
 // blocks) (1+skew) tall, the "slow" ones (1-skew) tall, so that all slots are used and the two
 // workgroups of a CU finish together.  Placement only affects speed; the items tile the rows exactly.
-// Returns {strip, row_begin, row_end} triples in block order; empty when the geometry does not
-// qualify (the regular grid is used instead).
-std::vector<int> plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct)
+// With ONE workgroup per CU (the pipelined split-f16 kernel) there are n_cu items of plain equal height
+// per strip.  Returns {strip, row_begin, row_end} triples in block order; empty when the geometry does
+// not qualify (the regular grid is used instead).
+std::vector<int> plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2)
 {
     const std::vector<int> none;
-    const int rows = row_end - row_begin, slots = 2 * n_cu;
+    const int rows = row_end - row_begin, slots = wgs_per_cu * n_cu;
     if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu || slots / n_strips < 2 ||
         rows / (slots / n_strips + 1) < 24)
         return none;
+    if (wgs_per_cu == 1) skew_pct = 0;
     const int kbase = slots / n_strips, kextra = slots % n_strips;      // strips [0,kextra) get kbase+1 items
     std::vector<int> k(n_strips), a(n_strips);
     int fast_total = 0;
     for (int s = 0; s < n_strips; ++s) {
         k[s] = kbase + (s < kextra ? 1 : 0);
-        a[s] = k[s] / 2;
+        a[s] = wgs_per_cu == 1 ? k[s] : k[s] / 2;
         fast_total += a[s];
     }
     for (int s = 0; fast_total < n_cu && s < n_strips; ++s)              // odd counts first, then any
@@ -349,15 +351,15 @@ int skew_percent()
 }
 
 // Device copy of plan_items(), cached for the last geometry.  *n_items = 0: use the regular grid.
-int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int *n_items)
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, int *n_items)
 {
     *n_items = 0;
-    const int key[5] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu};
+    const int key[6] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu};
     if (c->items_key[0] && std::memcmp(key, c->items_key, sizeof(key)) == 0) {
         *n_items = c->items_count;
         return SRCNN_OK;
     }
-    const std::vector<int> items = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3]);
+    const std::vector<int> items = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu);
     if (!items.empty()) {
         int rc;
         HIP_TRY(c, hipDeviceSynchronize());                             // an earlier launch may still read the table
@@ -370,11 +372,22 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int *n_i
     return SRCNN_OK;
 }
 
+// The split-f16 kernel runs one workgroup per CU (its software-pipelined form, srcnn_split16.hip);
+// SRCNN_DEBUG_TUNE bit 4 selects the earlier two-workgroups-per-CU form for comparison.
+int split16_wgs_per_cu(bool split16, int tune) { return (split16 && !(tune & 16)) ? 1 : 2; }
+
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
     const int halo = (mode == MODE_L12) ? 0 : 2;
-    Plan pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo);
+    // undocumented experiment knobs (never set in production)
+    static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
+    static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
+    p.tune = env_tune ? std::atoi(env_tune) : 0;
+    const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
+    const bool split16 = mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16;
+    const int wgs_per_cu = split16_wgs_per_cu(split16, p.tune);
+    Plan pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo, wgs_per_cu);
     static const char *env_segs = std::getenv("SRCNN_DEBUG_SEGS");     // experiment knob
     if (env_segs && std::atoi(env_segs) > 0) {
         const int rows = p.row_end - p.row_begin, ns = std::min(rows, std::atoi(env_segs));
@@ -389,7 +402,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
     if (mode != MODE_L12 && n_frames == 1) {
-        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, &grid_items);
+        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, &grid_items);
         if (rc) return rc;
         if (grid_items > 0) {
             p.items = static_cast<const int *>(c->items.p);
@@ -401,12 +414,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.wfrag16 = static_cast<const uint32_t *>(c->wfrag16.p);
     p.sink = static_cast<float *>(c->sink.p);
     p.b3 = c->b3;
-    // undocumented experiment knobs (never set in production)
-    static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
-    static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
-    p.tune = env_tune ? std::atoi(env_tune) : 0;
-    const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
-    if (mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16) {
+    if (split16) {
         if (!c->split16_ok)
             return fail(c, SRCNN_ERR_STATE, "SRCNN_MODE_SPLIT16: these weights exceed the f16 ranges of the mode "
                                             "(layer maps must stay below 8192 / 16384 for 8-bit input); use SRCNN_MODE_MFMA");
@@ -589,13 +597,15 @@ int srcnn_debug_read_sink(srcnn_ctx *c, void *dst, size_t bytes)
 int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[6])
 {
     if (!c || !out || width <= 0 || height <= 0 || n_frames <= 0) return SRCNN_ERR_INVALID;
-    const Plan pl = make_plan(c, width, height, n_frames, 2);
+    static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
+    const int wgs_per_cu = split16_wgs_per_cu(c->mode == SRCNN_MODE_SPLIT16, env_tune ? std::atoi(env_tune) : 0);
+    const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu);
     out[0] = pl.n_strips * pl.n_segs * n_frames;
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
     if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
-        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent());
+        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu);
         if (!items.empty()) {
             out[0] = (int)items.size() / 3;
             out[1] = 0;

@@ -780,7 +780,7 @@ hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
     const size_t lds = split16_lds_bytes() + lds_pad;
-    if (p.tune & 4) {       // experiment: software-pipelined variant, one workgroup per CU
+    if (!(p.tune & 16)) {   // default: software-pipelined kernel, one workgroup per CU (bit 4: the two-per-CU form)
         const size_t ldsp = split16p_lds_bytes() + lds_pad;
         if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16p_kernel<false, true>), grid, block, ldsp, stream, p);
         else if (p.pre) hipLaunchKernelGGL((srcnn_split16p_kernel<true>), grid, block, ldsp, stream, p);
