@@ -682,14 +682,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
         n1 = MFMA16(w1[1][1][1], BV(1), n1); SIMPLE1(3, 3, n1); MIX1(2, 3); PIN();
         if constexpr (DIAG) { q1 = stampp(); PIN(); }
         // g17-g21 | mix quad 3; B operands of row f+2 (rows up to f+6 are staged and published)
-        d2 = MFMA16(w2[0][2], bl1(2), d2); after(d2); MIX1(3, 0); read_b_part(f + 2, bqn, 0); PIN();
-        d2 = MFMA16(w2[0][3], bh1(3), d2); after(d2); MIX1(3, 1); read_b_part(f + 2, bqn, 1); PIN();
-        d2 = MFMA16(w2[1][3], bh1(3), d2); after(d2); MIX1(3, 2); read_b_part(f + 2, bqn, 2); PIN();
-        n0 = MFMA16(w1[0][0][2], BV(2), n0); after(n0); MIX1(3, 3); read_b_part(f + 2, bqn, 3); PIN();
-        d2 = MFMA16(w2[0][3], bl1(3), d2); after(d2); read_b_part(f + 2, bqn, 4); PIN();
+        d2 = MFMA16(w2[0][2], bl1(2), d2); after(d2); MIX1(3, 0); PIN();
+        d2 = MFMA16(w2[0][3], bh1(3), d2); after(d2); MIX1(3, 1); PIN();
+        d2 = MFMA16(w2[1][3], bh1(3), d2); after(d2); MIX1(3, 2); PIN();
+        n0 = MFMA16(w1[0][0][2], BV(2), n0); after(n0); MIX1(3, 3); PIN();
+        d2 = MFMA16(w2[0][3], bl1(3), d2); after(d2); PIN();
         // g22-g23: layer 1 while the layer-2 result completes | Y staging, output of the previous row
-        n1 = MFMA16(w1[1][0][2], BV(2), n1); after(n1); stage_y(f + 7, (uint8_t)ynext); PIN();
-        n0 = MFMA16(w1[0][1][2], BV(2), n0); after(n0); hp_use(g, 0, hp); PIN();
+        n1 = MFMA16(w1[1][0][2], BV(2), n1); after(n1); PIN();
+        n0 = MFMA16(w1[0][1][2], BV(2), n0); after(n0); PIN();
         if constexpr (DIAG) { q2 = stampp(); PIN(); }
         // g24-g29: layer 1 | rescale + bias of the layer-2 result, simple steps of its quad 0
         n1 = MFMA16(w1[1][1][2], BV(2), n1); after(n1); s2e(0); PIN();
@@ -704,15 +704,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
         n1 = MFMA16(w1[1][0][4], BV(4), n1); SIMPLE2(1, 2, n1); MIX2(0, 2); PIN();
         n0 = MFMA16(w1[0][1][4], BV(4), n0); SIMPLE2(1, 3, n0); MIX2(0, 3); PIN();
         // g34-g38 | mix quad 1
-        t = MFMA16(w3[0][0], bl2(0), t); after(t); MIX2(1, 0); PIN();
-        t = MFMA16(w3[0][1], bh2(1), t); after(t); MIX2(1, 1); PIN();
-        t = MFMA16(w3[1][1], bh2(1), t); after(t); MIX2(1, 2); PIN();
-        n1 = MFMA16(w1[1][1][4], BV(4), n1); after(n1); MIX2(1, 3); PIN();
-        t = MFMA16(w3[0][1], bl2(1), t); after(t); PIN();
+        t = MFMA16(w3[0][0], bl2(0), t); after(t); MIX2(1, 0); read_b_part(f + 2, bqn, 0); PIN();
+        t = MFMA16(w3[0][1], bh2(1), t); after(t); MIX2(1, 1); read_b_part(f + 2, bqn, 1); PIN();
+        t = MFMA16(w3[1][1], bh2(1), t); after(t); MIX2(1, 2); read_b_part(f + 2, bqn, 2); PIN();
+        n1 = MFMA16(w1[1][1][4], BV(4), n1); after(n1); MIX2(1, 3); read_b_part(f + 2, bqn, 3); PIN();
+        t = MFMA16(w3[0][1], bl2(1), t); after(t); read_b_part(f + 2, bqn, 4); PIN();
         if constexpr (DIAG) { q3 = stampp(); PIN(); }
         // g39-g42: the last layer-1 MFMAs; t is complete when they are through
-        n0 = MFMA16(w1[0][0][5], BV(5), n0); PIN();
-        n1 = MFMA16(w1[1][0][5], BV(5), n1); PIN();
+        n0 = MFMA16(w1[0][0][5], BV(5), n0); after(n0); stage_y(f + 7, (uint8_t)ynext); PIN();
+        n1 = MFMA16(w1[1][0][5], BV(5), n1); after(n1); hp_use(g, 0, hp); PIN();
         n0 = MFMA16(w1[0][1][5], BV(5), n0); PIN();
         n1 = MFMA16(w1[1][1][5], BV(5), n1); PIN();
 #undef SIMPLE1
