@@ -493,34 +493,31 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
         }
     };
     auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
+    // Branch-free: the row loop carries no control flow around the chains.  The image's FIRST feature row
+    // (rows -1, -2 replicate row 0, src/srcnn.cpp:203: output rows 0 and 1 start with taps m = 0..2 resp.
+    // m = 0..1 all taken from row 0) is folded in with a 0/1 factor: top * x is exact, so
+    // fma(top, t0, t1) == t0 + t1 and fma(-top, t3, t3) == 0 bit for bit.
     auto vertical = [&](int f, const f32x16 &t) {
-        const int fplane = 3 * half * FW + xi;
-        if (f > 0) {
-            float *fo = ftile(f, 0) + fplane;
+        float *fo = ftile(f, 0) + 3 * half * FW + xi;
+        const float top = f == 0 ? 1.f : 0.f;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                fo[s * FW] = R[3][s] + t[5 * s + 4];
-                R[3][s] = R[2][s] + t[5 * s + 3];
-                R[2][s] = R[1][s] + t[5 * s + 2];
-                R[1][s] = R[0][s] + t[5 * s + 1];
-                R[0][s] = t[5 * s];
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                R[0][s] = t[5 * s];
-                R[1][s] = t[5 * s] + t[5 * s + 1];
-                R[2][s] = R[1][s] + t[5 * s + 2];
-                R[3][s] = 0.f;
-            }
+        for (int s = 0; s < 3; ++s) {
+            fo[s * FW] = R[3][s] + t[5 * s + 4];            // output row f-2: taps m=0..3 + m=4
+            const float t01 = t[5 * s] + t[5 * s + 1];
+            R[3][s] = __builtin_fmaf(-top, t[5 * s + 3], R[2][s] + t[5 * s + 3]);
+            R[2][s] = __builtin_fmaf(top, t01, R[1][s] + t[5 * s + 2]);
+            R[1][s] = __builtin_fmaf(top, t[5 * s], R[0][s] + t[5 * s + 1]);
+            R[0][s] = t[5 * s];
         }
-        if (f == H - 1) {
-            float *f1 = ftile(f, 1) + fplane, *f2 = ftile(f, 2) + fplane;
+    };
+    // The image's LAST feature row (rows H, H+1 replicate row H-1) also supplies m = 4 of output row H-2
+    // and m = 3, 4 of output row H-1; it is always the last row of its work item, i.e. part of the drain.
+    auto vertical_bottom = [&](int f, const f32x16 &t) {
+        float *f1 = ftile(f, 1) + 3 * half * FW + xi, *f2 = ftile(f, 2) + 3 * half * FW + xi;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                f1[s * FW] = R[3][s] + t[5 * s + 4];
-                f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
-            }
+        for (int s = 0; s < 3; ++s) {
+            f1[s * FW] = R[3][s] + t[5 * s + 4];
+            f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
         }
     };
     float hv[5];
@@ -609,13 +606,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
     };
     // One row: consume (c0, c1) = layer-1 result of row f, produce (n0, n1) = layer 1 of row f+1 from the
     // B operands bq (read during the previous row); read the B operands of row f+2 into bqn.
-    auto row = [&](int f, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, unsigned (&bq)[24], unsigned (&bqn)[24]) {
-        const int g = f - 1;
+    // The layer-3 tap partials t of row f are folded into the vertical chains at the START of row f+1
+    // (tp = partials of row f-1), so their F-tile writes are long complete at the barrier that ends the
+    // row; the horizontal sum / output therefore lags two rows (g = f-2).
+    auto row = [&](int f, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, unsigned (&bq)[24], unsigned (&bqn)[24],
+                   const f32x16 &tp, f32x16 &t) {
+        const int g = f - 2;
         const bool hp = g >= f_lo;
         unsigned ynext = load_y(f + 7);
         unsigned h1[16], l1[16], h2[8], l2[8];
         float x1[32], e[16];
-        f32x16 d2 = {0}, t = {0};
+        f32x16 d2 = {0};
+        t = (f32x16){0};
         n0 = (f32x16){0};
         n1 = (f32x16){0};
 #pragma unroll
@@ -662,6 +664,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
     } while (0)
         // g1-g4: layer 1 of the next row | simple steps of quad 0; F tile reads of the previous row
         n0 = MFMA16(w1[0][0][0], BV(0), n0); SIMPLE1(0, 0, n0); hp_load(g, 0); PIN();
+        vertical(f - 1, tp);        // tp == 0 before the first row of the item: adds nothing
+        PIN();
         n1 = MFMA16(w1[1][0][0], BV(0), n1); SIMPLE1(0, 1, n1); PIN();
         n0 = MFMA16(w1[0][1][0], BV(0), n0); SIMPLE1(0, 2, n0); PIN();
         n1 = MFMA16(w1[1][1][0], BV(0), n1); SIMPLE1(0, 3, n1); PIN();
@@ -720,7 +724,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
 #undef SIMPLE2
 #undef MIX2
         if constexpr (DIAG) { q4 = stampp(); PIN(); }
-        vertical(f, t);
         lds_barrier16();
         if constexpr (DIAG) {
             q5 = stampp();
@@ -733,24 +736,32 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dg_t0)::"memory");
         dg_r0 = __builtin_amdgcn_s_memrealtime();
     }
+    f32x16 tA = {0}, tB = {0};
     int f = f_lo;
+    bool last_in_a = false;            // which of tA / tB holds the partials of the last row
     for (; f + 1 < f_hi; f += 2) {
-        row(f, accA0, accA1, accB0, accB1, bqB, bqA);
-        row(f + 1, accB0, accB1, accA0, accA1, bqA, bqB);
+        row(f, accA0, accA1, accB0, accB1, bqB, bqA, tB, tA);
+        row(f + 1, accB0, accB1, accA0, accA1, bqA, bqB, tA, tB);
     }
     if (f < f_hi) {
-        row(f, accA0, accA1, accB0, accB1, bqB, bqA);
+        row(f, accA0, accA1, accB0, accB1, bqB, bqA, tB, tA);
+        last_in_a = true;
         ++f;
     }
-    // drain: the horizontal sums of the last feature row (f == f_hi here)
-    {
+    // drain (f == f_hi): the output row that feature row f-2 completed, then the last feature row itself
+    if (f - 2 >= f_lo) {
+        hp_load(f - 2, 0);
+        hp_use(f - 2, 0, true);
+    }
+    if (f - 1 >= f_lo) {
+        vertical(f - 1, last_in_a ? tA : tB);
+        if (f - 1 == H - 1) vertical_bottom(f - 1, last_in_a ? tA : tB);
+        __syncthreads();
         const int g = f - 1;
-        if (g >= f_lo) {
-            const int nslots = (g == H - 1) ? 3 : 1;
-            for (int slot = 0; slot < nslots; ++slot) {
-                hp_load(g, slot);
-                hp_use(g, slot, true);
-            }
+        const int nslots = (g == H - 1) ? 3 : 1;
+        for (int slot = 0; slot < nslots; ++slot) {
+            hp_load(g, slot);
+            hp_use(g, slot, true);
         }
     }
     if constexpr (DIAG) {
