@@ -372,9 +372,8 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
     return SRCNN_OK;
 }
 
-// The split-f16 kernel runs one workgroup per CU (its software-pipelined form, srcnn_split16.hip);
-// SRCNN_DEBUG_TUNE bit 4 selects the earlier two-workgroups-per-CU form for comparison.
-int split16_wgs_per_cu(bool split16, int tune) { return (split16 && !(tune & 16)) ? 1 : 2; }
+// The split-f16 kernel is software-pipelined inside a wave and runs one workgroup per CU (srcnn_split16.hip).
+int split16_wgs_per_cu(bool split16, int /*tune*/) { return split16 ? 1 : 2; }
 
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)

@@ -8,13 +8,15 @@
 // result stays at float32-level accuracy:
 //
 //   w = w_hi + w_lo   (host, round-to-nearest; |w - w_hi - w_lo| <= 2^-22 |w|)
-//   a = a_hi + a_lo   (kernel: a_hi = rtz_f16(a), a_lo = f16(a - a_hi), one v_fma_mixlo/hi_f16 each)
+//   a = a_hi + a_lo   (kernel: a_hi = max(rtz_f16(a), 0), a_lo = clamp(f16(a - a_hi), 0, 1): v_cvt_pkrtz_f16_f32,
+//                      v_pk_max_f16, v_fma_mixlo/hi_f16 with the clamp bit -- ReLU comes for free: a - a_hi is
+//                      exact in f32, and for a < 0 both parts come out 0)
 //   w*a ~= w_hi*a_hi + w_lo*a_hi + w_hi*a_lo          (the dropped w_lo*a_lo is <= 2^-22 |w a|)
 //
 // f16 x f16 products are exact in the MFMA's f32 accumulation, so the only differences from the
 // f32 path are the 2^-22 truncations above and the summation order.  Layer 1 needs only two
 // products: its input is an 8-bit integer, exact in f16.  Power-of-two scales (exact) keep every f16
-// factor in the normal range and every activation below 1024 (needed by relu_split_pair):
+// factor in the normal range and every activation below 1024 (needed by the clamped split steps):
 //   Y staged as y * 2^-14, W1 as w * 2^11, b1 as b/8 (its B operand is 1.0)  -> layer-1 map / 8
 //   W2 as w * 2^14 -> accumulator = 2^11 * pre-bias; fma(acc, 2^-15, b2/16)  -> layer-2 map / 16
 //   W3 as w * 2^14 -> tap partials * 2^10, removed by the final fma(acc, 2^-10, b3).
@@ -54,324 +56,31 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float S16_UNSCALE_L2 = 3.0517578125e-05f;   // 2^-15
 constexpr float S16_UNSCALE_L3 = 9.765625e-04f;       // 2^-10
-constexpr int S16_YC = FW + 10;                 // staged ring columns: strip + 4 each side + the pair partner of tap 8
-constexpr int S16_RS = 144;                     // ring row pitch in halfs (even: rows stay dword aligned)
-constexpr int S16_CS = 2 * YR * S16_RS + 32;    // copy pitch in halfs (+16 dwords: the two copies hit disjoint banks)
-constexpr int S16_RING_BYTES = 2 * S16_CS * 2;
-
 __device__ __forceinline__ int clampi16(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 __device__ __forceinline__ void lds_barrier16() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ float relu16(float x)
-{
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-// ReLU + split of two f32 values into packed f16 pairs: hi = max(rtz_f16(x), 0), lo = clamp(f16(x - hi), 0, 1).
-// x - hi is exact in f32 (hi keeps the leading 11 bits of x), so hi + lo carries 22 bits of x.  For
-// x < 0 both come out 0: hi by the packed max, lo because x - 0 < 0 clamps to 0 -- the ReLU of
-// src/srcnn.cpp:304,319 costs one packed instruction per pair.  The clamp's upper end is never reached:
-// the kernel keeps its activations below 1024 (scales in the header comment), so 0 <= x - hi < 1.
-__device__ __forceinline__ void relu_split_pair(float x0, float x1, unsigned &hi, unsigned &lo)
-{
-    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-    const h2 h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-    unsigned raw = __builtin_bit_cast(unsigned, h);
-    asm("v_pk_max_f16 %0, %1, 0" : "=v"(hi) : "v"(raw));
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(lo) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(lo) : "v"(hi), "v"(x1));
-}
-
-template <bool PRE, bool DIAG = false>
-__global__ __launch_bounds__(NTHREADS, 2) void srcnn_split16_kernel(const StripParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][S16_RS]
-    float *fbuf = reinterpret_cast<float *>(smem + S16_RING_BYTES);       // [2][3][6][FW]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;
-    const int half = lane >> 5;
-
-    constexpr int HALO = 2;
-    constexpr int OWM = FW - 2 * HALO;
-    const int W = p.width, H = p.height;
-
-    // work mapping: identical to srcnn_strip_kernel (srcnn_mfma.hip)
-    int bid = blockIdx.x;
-    int strip, frame = 0, ys, ye;
-    if (p.items) {
-        const int *it = p.items + 3 * bid;
-        strip = it[0];
-        ys = it[1];
-        ye = it[2];
-    } else {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        strip = bid % p.n_strips;
-        bid /= p.n_strips;
-        const int seg = bid % p.n_segs;
-        frame = bid / p.n_segs;
-        ys = p.row_begin + seg * p.seg_rows;
-        ye = min(ys + p.seg_rows, p.row_end);
-    }
-    const int xs = strip * OWM;
-    const int gx0 = xs - HALO;
-    const int f_lo = max(ys - HALO, 0);
-    const int f_hi = min(ye + HALO, H);
-
-    // ---- weight fragments -> registers: 36 fragments x 4 VGPRs (pack_fragments16) ----
-    const u32x4 *wf = reinterpret_cast<const u32x4 *>(p.wfrag16) + lane;
-    u32x4 w1[2][2][6], w2[2][4], w3[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) w1[t][s][b] = wf[((t * 2 + s) * 6 + b) * 64];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w2[s][b] = wf[(S16_FRAG_L2 + s * 4 + b) * 64];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) w3[s][b] = wf[(S16_FRAG_L3 + s * 2 + b) * 64];
-    float b2v[16];
-    {
-        const float *bt = reinterpret_cast<const float *>(p.wfrag16 + S16_NFRAG * 64 * 4) + half * 16;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) b2v[r] = bt[r];
-    }
-
-    // ---- layer-1 input: rolling window of Y rows as f16 (y * 2^-14) in LDS, two copies ----
-    // Ring column c is image column clamp(gx0-4+c) (replicate border, src/srcnn.cpp:266-280);
-    // copy 0 holds column c at element c, copy 1 at element c-1.  Row r lives in slots r&15 and
-    // (r&15)+16 so that a 9-row window is contiguous (as in srcnn_mfma.hip).
-    const uint8_t *srcf = p.src + (long)frame * p.src_frame_pitch;
-    const int ycol = clampi16(gx0 - 4 + tid, 0, W - 1);
-    auto load_y = [&](int r) -> uint8_t {
-        const int rr = clampi16(r, 0, H - 1) - p.src_row0;
-        return srcf[(long)rr * p.src_stride + ycol];
-    };
-    auto stage_y = [&](int r, uint8_t v) {
-        const int slot = r & (YR - 1);
-        const _Float16 hv = (_Float16)((float)v * 6.103515625e-05f);      // exact: 8-bit integer * 2^-14
-        _Float16 *c0 = ring + slot * S16_RS + tid;
-        c0[0] = hv;
-        c0[YR * S16_RS] = hv;
-        if (tid > 0) {
-            _Float16 *c1 = ring + S16_CS + slot * S16_RS + tid - 1;
-            c1[0] = hv;
-            c1[YR * S16_RS] = hv;
-        }
-    };
-    if (tid < S16_YC) {
-        uint8_t v[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = load_y(f_lo - 4 + q);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) stage_y(f_lo - 4 + q, v[q]);
-    }
-    __syncthreads();
-
-    const int xi = 32 * wave + j;
-    const int gx = gx0 + xi;
-
-    // ---- layer 3 epilogue: identical scheme to srcnn_mfma.hip; values carry the factor 2^14 of W3 ----
-    int xn[5];
-#pragma unroll
-    for (int n = 0; n < 5; ++n) xn[n] = clampi16(clampi16(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
-    const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
-    float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    auto finalize = [&](int y, float acc, bool ok) {
-        const float v = __builtin_fmaf(acc, S16_UNSCALE_L3, p.b3);        // exact unscale, then + bias (one rounding)
-        const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
-        uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
-        *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
-        if constexpr (PRE) {
-            float *dp = ok ? p.pre + o : p.sink + 64 + lane;
-            *dp = v;
-        }
-    };
-    auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
-    auto vertical = [&](int f, const f32x16 &t) {
-        const int fplane = 3 * half * FW + xi;
-        if (f > 0) {
-            float *fo = ftile(f, 0) + fplane;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                fo[s * FW] = R[3][s] + t[5 * s + 4];
-                R[3][s] = R[2][s] + t[5 * s + 3];
-                R[2][s] = R[1][s] + t[5 * s + 2];
-                R[1][s] = R[0][s] + t[5 * s + 1];
-                R[0][s] = t[5 * s];
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                R[0][s] = t[5 * s];
-                R[1][s] = t[5 * s] + t[5 * s + 1];
-                R[2][s] = R[1][s] + t[5 * s + 2];
-                R[3][s] = 0.f;
-            }
-        }
-        if (f == H - 1) {
-            float *f1 = ftile(f, 1) + fplane, *f2 = ftile(f, 2) + fplane;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                f1[s * FW] = R[3][s] + t[5 * s + 4];
-                f2[s * FW] = (R[2][s] + t[5 * s + 3]) + t[5 * s + 4];
-            }
-        }
-    };
-    auto horizontal = [&](int g, int slot) {
-        const float *fr = ftile(g, slot);
-        float acc = fr[xn[0]];
-#pragma unroll
-        for (int n = 1; n < 5; ++n) acc += fr[n * FW + xn[n]];
-        const int y = g - 2 + slot;
-        finalize(y, acc, px_ok && (y >= ys) && (y < ye));
-    };
-
-    const int ring_lane = (xi & 1) * S16_CS + (xi & ~1);     // halfs; even -> dword aligned
-    // DIAG build only (SRCNN_DEBUG_TUNE & 2): cycle stamps -> p.sink, never an output
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        return t;
-    };
-    unsigned long long dg[6] = {0, 0, 0, 0, 0, 0}, dg_t0 = 0, dg_r0 = 0;
-    if constexpr (DIAG) {
-        dg_t0 = stamp();
-        dg_r0 = __builtin_amdgcn_s_memrealtime();
-    }
-    for (int f = f_lo; f <= f_hi; ++f) {
-        const bool do_a = f < f_hi;
-        const int g = f - 1;
-        const bool hp = g >= f_lo;
-        if (!do_a) {
-            if (hp) {
-                const int nslots = (g == H - 1) ? 3 : 1;
-                for (int slot = 0; slot < nslots; ++slot) horizontal(g, slot);
-            }
-            break;
-        }
-        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-        if constexpr (DIAG) s0 = stamp();
-        unsigned ynext = 0;
-        if (tid < S16_YC && !(p.tune & 32)) ynext = load_y(f + 5);
-
-        // ---------------- layer 1: 24 MFMA -----------------------------------------------------
-        const unsigned *yb = reinterpret_cast<const unsigned *>(ring + ring_lane + ((f - 4) & (YR - 1)) * S16_RS);
-        const unsigned *ybH = yb + half * (5 * S16_RS / 2);          // rows 0-3 | rows 5-8
-        const unsigned *ybX = yb + 4 * (S16_RS / 2) + 2 * half;      // row 4: taps 0-5 | taps 4-9
-        unsigned bq[24];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int q = 0; q < 5; ++q) bq[rr * 5 + q] = ybH[rr * (S16_RS / 2) + q];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) bq[20 + q] = ybX[q];
-        bq[23] = 0x00003C00u;                                        // (1.0, 0): the bias slot
-        f32x16 a0 = {0}, a1 = {0};
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const u32x4 bv = {bq[4 * b], bq[4 * b + 1], bq[4 * b + 2], bq[4 * b + 3]};
-            a0 = MFMA16(w1[0][0][b], bv, a0);
-            a1 = MFMA16(w1[1][0][b], bv, a1);
-            a0 = MFMA16(w1[0][1][b], bv, a0);
-            a1 = MFMA16(w1[1][1][b], bv, a1);
-        }
-        if constexpr (DIAG) { asm volatile("" :: "v"(a0[0]), "v"(a1[0])); s1 = stamp(); }
-        // the horizontal 5-term sum of the row completed one iteration ago
-        if (hp && !(p.tune & 64)) horizontal(g, 0);
-
-        // ReLU (src/srcnn.cpp:304) + split into f16 hi/lo pairs: the layer-2 B operands
-        unsigned h1[16], l1[16];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            relu_split_pair(a0[2 * q], a0[2 * q + 1], h1[q], l1[q]);
-            relu_split_pair(a1[2 * q], a1[2 * q + 1], h1[8 + q], l1[8 + q]);
-        }
-
-        // ---------------- layer 2: 12 MFMA -----------------------------------------------------
-        f32x16 d2 = {0};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const u32x4 bh = {h1[4 * b], h1[4 * b + 1], h1[4 * b + 2], h1[4 * b + 3]};
-            const u32x4 bl = {l1[4 * b], l1[4 * b + 1], l1[4 * b + 2], l1[4 * b + 3]};
-            d2 = MFMA16(w2[0][b], bh, d2);
-            d2 = MFMA16(w2[1][b], bh, d2);
-            d2 = MFMA16(w2[0][b], bl, d2);
-        }
-        if constexpr (DIAG) { asm volatile("" :: "v"(d2[0])); s2 = stamp(); }
-        // rescale (exact) + bias, ReLU (src/srcnn.cpp:316-319) + split for layer 3
-        unsigned h2[8], l2[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            relu_split_pair(__builtin_fmaf(d2[2 * q], S16_UNSCALE_L2, b2v[2 * q]),
-                            __builtin_fmaf(d2[2 * q + 1], S16_UNSCALE_L2, b2v[2 * q + 1]), h2[q], l2[q]);
-
-        // ---------------- layer 3 tap partials: 6 MFMA -----------------------------------------
-        f32x16 t = {0};
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const u32x4 bh = {h2[4 * b], h2[4 * b + 1], h2[4 * b + 2], h2[4 * b + 3]};
-            const u32x4 bl = {l2[4 * b], l2[4 * b + 1], l2[4 * b + 2], l2[4 * b + 3]};
-            t = MFMA16(w3[0][b], bh, t);
-            t = MFMA16(w3[1][b], bh, t);
-            t = MFMA16(w3[0][b], bl, t);
-        }
-        if constexpr (DIAG) { asm volatile("" :: "v"(t[0])); s3 = stamp(); }
-        if (!(p.tune & 64)) vertical(f, t);
-
-        asm volatile("" : "+v"(ynext));
-        if (tid < S16_YC && !(p.tune & 32)) stage_y(f + 5, (uint8_t)ynext);
-        if constexpr (DIAG) s4 = stamp();
-        if (!(p.tune & 16)) lds_barrier16();
-        if constexpr (DIAG) {
-            const unsigned long long s5 = stamp();
-            dg[0] += s1 - s0; dg[1] += s2 - s1; dg[2] += s3 - s2; dg[3] += s4 - s3; dg[4] += s5 - s4;
-        }
-    }
-    if constexpr (DIAG) {
-        const unsigned long long t1 = stamp();
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) + ((long)blockIdx.x * NWAVES + wave) * 8;
-            o[0] = t1 - dg_t0;
-            o[1] = r1 - dg_r0;
-            o[2] = dg[0]; o[3] = dg[1]; o[4] = dg[2]; o[5] = dg[3];
-            o[6] = (unsigned long long)(f_hi - f_lo) | ((dg_r0 & 0xffffffffull) << 32);
-            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | (dg[4] << 32);
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Software-pipelined variant: ONE workgroup per CU (one wave per SIMD, 512 registers per lane).
-// With a single wave on the SIMD nothing else hides a wave's vector work, so the row loop is
-// pipelined inside the wave: while the vector chain of row f runs (split -> layer 2 -> split ->
-// layer 3), the 24 layer-1 MFMAs of row f+1 -- which depend on nothing in that chain -- are issued
-// between its steps.  Program order is the schedule: every MFMA is followed by at most one
-// relu_split_pair (4 vector instructions, what fits in the 24 free issue cycles of a 32-cycle f16
-// MFMA, tools/f16_probe.hip) and sched_barrier(0) keeps the compiler from regrouping.  Two
-// accumulator sets alternate between "being converted" and "being accumulated" (the loop is
-// unrolled by two), rows are staged two ahead so that the B operands of row f+2 are read before the
-// barrier that ends iteration f.
+// Schedule.  ONE workgroup per CU = one wave per SIMD with all 512 registers of a lane: the 36 weight
+// fragments (144 registers) live in the accumulation-register half (they are only ever MFMA A operands),
+// everything the vector ALU touches in the 256 architectural VGPRs (built with -amdgpu-mfma-vgpr-form so
+// that MFMA results land there, srcnn_cpp_amd/build.py).  With a single wave on the SIMD nothing else
+// hides a wave's vector work, so the row loop is software-pipelined inside the wave: while the dependent
+// chain of row f runs (split -> layer 2 -> rescale/split -> layer 3), the 24 layer-1 MFMAs of row f+1,
+// which depend on nothing in that chain, are issued between its steps.  Program order is the schedule:
+// each of the 42 MFMAs of a row is followed by the vector work that fits in its shadow (24 issue cycles;
+// two 8-cycle v_fma_mix plus two 4-cycle instructions, all independent of each other: tools/f16_probe.hip)
+// and sched_barrier(0) keeps the compiler from regrouping.  Two accumulator / B-operand / tap-partial
+// register sets alternate between "being converted" and "being accumulated" (loop unrolled by two), Y rows
+// are staged two ahead so that the B operands of row f+2 are read before the barrier that ends row f, the
+// vertical tap sums of row f are folded in at the start of row f+1 (branch-free), and the finished output
+// row leaves two rows behind.  An earlier form with two workgroups per CU and no pipelining measured 5-8 %
+// slower (profiles/r01/split16_ablation.txt).
 constexpr int SP_RS = 264;                      // ring row pitch in halfs: every thread stages its own column
 constexpr int SP_CS = 2 * YR * SP_RS + 32;
 constexpr int SP_RING_BYTES = 2 * SP_CS * 2;
 
 template <bool PRE, bool DIAG = false>
-__global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const StripParams p)
+__global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][SP_RS]
@@ -783,21 +492,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16p_kernel(const Strip
 
 }  // namespace
 
-size_t split16_lds_bytes() { return (size_t)S16_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
-size_t split16p_lds_bytes() { return (size_t)SP_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
+size_t split16_lds_bytes() { return (size_t)SP_RING_BYTES + sizeof(float) * 2 * 3 * 6 * FW; }
 
 hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
     const size_t lds = split16_lds_bytes() + lds_pad;
-    if (!(p.tune & 16)) {   // default: software-pipelined kernel, one workgroup per CU (bit 4: the two-per-CU form)
-        const size_t ldsp = split16p_lds_bytes() + lds_pad;
-        if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16p_kernel<false, true>), grid, block, ldsp, stream, p);
-        else if (p.pre) hipLaunchKernelGGL((srcnn_split16p_kernel<true>), grid, block, ldsp, stream, p);
-        else hipLaunchKernelGGL((srcnn_split16p_kernel<false>), grid, block, ldsp, stream, p);
-        return hipGetLastError();
-    }
     if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16_kernel<false, true>), grid, block, lds, stream, p);
     else if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((srcnn_split16_kernel<false>), grid, block, lds, stream, p);

@@ -26,9 +26,11 @@ rows = (raw[:, 6] & np.uint64(0xffff)).astype(float)
 bar = (raw[:, 7] >> np.uint64(32)).astype(float)
 slot = (raw[:, 7] & np.uint64(0xf)).astype(int)
 print(f"waves {n} rows/wave {rows.mean():.1f}; in-kernel clock GHz median {np.median(tot/real*100e6)/1e9:.3f}")
-print(f"cycles per row per wave: median {np.median(tot/rows):.0f}  (MFMA only: 42 x 32 = 1344; two waves share a SIMD)")
-for name, col in [("Y prefetch + B reads + layer 1 (24 MFMA)", 2), ("ReLU/split + layer 2 (12 MFMA)", 3), ("bias/ReLU/split + layer 3 (6 MFMA)", 4), ("vertical sums, F tile, Y staging", 5)]:
+print(f"cycles per row per wave: median {np.median(tot/rows):.0f}  (MFMA only: 42 x 32 = 1344; one wave per SIMD)")
+for name, col, n_mfma in [("MFMA 1-16  (split of the layer-1 result, vertical sums of the previous row)", 2, 16),
+                          ("MFMA 17-23 (end of layer 2)", 3, 7), ("MFMA 24-38 (rescale + split of the layer-2 result, B reads)", 4, 15),
+                          ("MFMA 39-42 (Y staging, output row)", 5, 4)]:
     v = raw[:, col].astype(float) / rows
-    print(f"  {name:44s} median {np.median(v):7.0f}  slot0 {np.median(v[slot == 0]):7.0f}  slot1 {np.median(v[slot != 0]):7.0f}")
-print(f"  {'barrier':44s} median {np.median(bar/rows):7.0f}")
-print("lifetime slot0 / slot1:", np.median(tot[slot == 0]), np.median(tot[slot != 0]))
+    print(f"  {name:78s} median {np.median(v):6.0f} = {np.median(v) / n_mfma:5.1f} per MFMA")
+print(f"  {'barrier + loop head':78s} median {np.median(bar/rows):6.0f}")
+print("(each section boundary costs one s_memtime + s_waitcnt in this DIAG build)")
