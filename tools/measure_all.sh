@@ -15,4 +15,8 @@ run --steps 5 --path host --frames 32                           # stream of host
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode
+run --steps 50 --mode split16                                   # opt-in split-f16 mode, 1 x 3840x2160
+run --steps 5 --mode split16 --frames 64                        # opt-in split-f16 mode, 64 x 3840x2160
+run --steps 20 --mode split16 --path pipeline                   # BGR 1080p -> BGR 4K with the split-f16 conv path
+run --steps 5 --mode split16 --path host --frames 32            # host frame stream with the split-f16 conv path
 cat $OUT
