@@ -49,10 +49,17 @@ struct srcnn_ctx {
     DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
     int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
     // second lane of the host-frame pipeline (srcnn_forward_y_frames)
-    // explicit work items of single-round launches (build_items), cached per geometry
-    DevBuf items;
-    int items_key[6] = {0, 0, 0, 0, 0, 0};
-    int items_count = 0;
+    // explicit work items of single-round launches (build_items): a small cache of device tables, one per
+    // launch geometry, so that a caller alternating between a few plane sizes never waits for an upload
+    struct ItemTable {
+        int key[6] = {0, 0, 0, 0, 0, 0};
+        int count = 0;                  // 0: this geometry uses the regular grid
+        DevBuf dev;
+        unsigned long stamp = 0;        // last use, for eviction
+    };
+    static constexpr int kItemTables = 8;
+    ItemTable item_tables[kItemTables];
+    unsigned long item_clock = 0;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
@@ -350,25 +357,36 @@ int skew_percent()
     return env_skew ? std::atoi(env_skew) : 10;
 }
 
-// Device copy of plan_items(), cached for the last geometry.  *n_items = 0: use the regular grid.
-int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, int *n_items)
+// Device copy of plan_items() for this geometry, from the context's table cache.  *n_items = 0: use the
+// regular grid.  A table is written once, before its first use, into memory no earlier launch reads
+// (a fresh slot, or an evicted one after its last reader has finished), and never modified afterwards.
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, int *n_items, const int **d_items)
 {
     *n_items = 0;
+    *d_items = nullptr;
     const int key[6] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu};
-    if (c->items_key[0] && std::memcmp(key, c->items_key, sizeof(key)) == 0) {
-        *n_items = c->items_count;
-        return SRCNN_OK;
+    srcnn_ctx::ItemTable *victim = &c->item_tables[0];
+    for (auto &t : c->item_tables) {
+        if (t.stamp && std::memcmp(key, t.key, sizeof(key)) == 0) {
+            t.stamp = ++c->item_clock;
+            *n_items = t.count;
+            *d_items = static_cast<const int *>(t.dev.p);
+            return SRCNN_OK;
+        }
+        if (t.stamp < victim->stamp) victim = &t;
     }
     const std::vector<int> items = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu);
     if (!items.empty()) {
         int rc;
-        HIP_TRY(c, hipDeviceSynchronize());                             // an earlier launch may still read the table
-        if ((rc = reserve(c, c->items, items.size() * sizeof(int)))) return rc;
-        HIP_TRY(c, hipMemcpy(c->items.p, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());          // evicting: its readers must be done
+        if ((rc = reserve(c, victim->dev, items.size() * sizeof(int)))) return rc;
+        HIP_TRY(c, hipMemcpy(victim->dev.p, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    std::memcpy(c->items_key, key, sizeof(key));
-    c->items_count = (int)items.size() / 3;
-    *n_items = c->items_count;
+    std::memcpy(victim->key, key, sizeof(key));
+    victim->count = (int)items.size() / 3;
+    victim->stamp = ++c->item_clock;
+    *n_items = victim->count;
+    *d_items = static_cast<const int *>(victim->dev.p);
     return SRCNN_OK;
 }
 
@@ -401,10 +419,11 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
     if (mode != MODE_L12 && n_frames == 1) {
-        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, &grid_items);
+        const int *d_items = nullptr;
+        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, &grid_items, &d_items);
         if (rc) return rc;
         if (grid_items > 0) {
-            p.items = static_cast<const int *>(c->items.p);
+            p.items = d_items;
             p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
             p.n_segs = grid_items;
         }
@@ -531,8 +550,9 @@ void srcnn_destroy(srcnn_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
-                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->items, &c->wfrag16})
+                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16})
         release(*b);
+    for (auto &t : c->item_tables) release(t.dev);
     for (int k = 0; k < 2; ++k) {
         release(c->lane_in[k]);
         release(c->lane_out[k]);
