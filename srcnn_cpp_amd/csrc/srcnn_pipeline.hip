@@ -127,6 +127,77 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled_kernel(const uint8_t *
     }
 }
 
+// Second tiling: a workgroup produces a 256 x 32 output tile and every thread FOUR adjacent pixels of 8 rows, so
+// the vertical pass reads its taps as one 16-byte LDS word per row and stores one dword per row: a quarter of the
+// store and LDS instructions of the kernel above (which remains the fallback for small scales / odd strides).
+// Same integer arithmetic, bit-identical results.
+constexpr int RT4 = 32;       // output rows per workgroup
+constexpr int RMAX4 = 28;     // source rows such a tile may span (host checks)
+
+__global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t *__restrict__ src, long sstride,
+                                                                  long spitch, int sw, int sh,
+                                                                  uint8_t *__restrict__ dst, long dstride, long dpitch,
+                                                                  int dw, int dh, const int *__restrict__ xofs,
+                                                                  const short *__restrict__ alpha,
+                                                                  const int *__restrict__ yofs,
+                                                                  const short *__restrict__ beta)
+{
+    __shared__ __attribute__((aligned(16))) int hbuf[RMAX4][256];
+    __shared__ uint8_t sbuf[RMAX4][SMAX];
+    const int tid = threadIdx.x;
+    const int dx0 = blockIdx.x * 256;
+    const int dy0 = blockIdx.y * RT4, dy1 = min(dy0 + RT4, dh);
+    const uint8_t *s = src + (long)blockIdx.z * spitch;
+    const int r_lo = yofs[dy0] - 1, r_hi = yofs[dy1 - 1] + 2;
+    const int c_lo = xofs[dx0] - 1, c_hi = xofs[min(dx0 + 255, dw - 1)] + 2;
+    const int ncol = c_hi - c_lo + 1, nrow = r_hi - r_lo + 1;
+    for (int e = tid; e < nrow * ncol; e += 256) {
+        const int rr = e / ncol, cc = e - rr * ncol;
+        sbuf[rr][cc] = s[(long)min(max(r_lo + rr, 0), sh - 1) * sstride + min(max(c_lo + cc, 0), sw - 1)];
+    }
+    __syncthreads();
+    {   // horizontal pass: thread = output column, all source rows of the tile
+        const int dxc = min(dx0 + tid, dw - 1);
+        const int x0 = xofs[dxc] - 1 - c_lo;
+        int a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = alpha[4 * dxc + k];
+        for (int rr = 0; rr < nrow; ++rr) {
+            int t = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t += sbuf[rr][x0 + k] * a[k];
+            hbuf[rr][tid] = t;
+        }
+    }
+    __syncthreads();
+    // vertical pass: thread (tx, ty) = columns 4tx..4tx+3 of rows dy0 + 8ty .. +7
+    const int tx = tid & 63, ty = tid >> 6;
+    const int dx = dx0 + 4 * tx;
+    if (dx >= dw) return;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const bool vec_ok = (dx + 3 < dw);
+    for (int r = 0; r < 8; ++r) {
+        const int dy = dy0 + 8 * ty + r;
+        if (dy >= dy1) break;
+        const int j = yofs[dy] - 1 - r_lo;
+        i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const i32x4 h = *reinterpret_cast<const i32x4 *>(&hbuf[j + k][4 * tx]);
+            acc += h * (int)beta[4 * dy + k];
+        }
+        uint8_t *o = dst + (long)blockIdx.z * dpitch + (long)dy * dstride + dx;
+        unsigned px[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) px[c] = sat8((acc[c] + (1 << 21)) >> 22);
+        if (vec_ok) {
+            *reinterpret_cast<unsigned *>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        } else {
+            for (int c = 0; c < 4 && dx + c < dw; ++c) o[c] = (uint8_t)px[c];
+        }
+    }
+}
+
 hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,
                             long ppitch, hipStream_t st)
 {
@@ -150,7 +221,12 @@ hipError_t launch_resize_cubic(const uint8_t *src, long sstride, long spitch, in
     // a tile of RT output rows spans at most ceil(RT * sh / dh) + 4 source rows (4-tap support)
     const long span = ((long)RT * sh + dh - 1) / dh + 4;
     const long cspan = (256L * sw + dw - 1) / dw + 5;      // likewise for 256 output columns
-    if (span <= RMAX && cspan <= SMAX)
+    const long span4 = ((long)RT4 * sh + dh - 1) / dh + 4;
+    const bool dword_ok = ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dstride | (uintptr_t)dpitch) & 3) == 0;
+    if (span4 <= RMAX4 && cspan <= SMAX && dword_ok)
+        hipLaunchKernelGGL(resize_cubic_tiled4_kernel, dim3((dw + 255) / 256, (dh + RT4 - 1) / RT4, n_planes), dim3(256),
+                           0, st, src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, xofs, alpha, yofs, beta);
+    else if (span <= RMAX && cspan <= SMAX)
         hipLaunchKernelGGL(resize_cubic_tiled_kernel, dim3((dw + 255) / 256, (dh + RT - 1) / RT, n_planes), dim3(256),
                            0, st, src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, xofs, alpha, yofs, beta);
     else
