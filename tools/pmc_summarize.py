@@ -56,3 +56,16 @@ for mode, kname in KERNEL.items():
     with open(os.path.join(out, f"{mode}_4k_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print(mode, json.dumps(d), "avg_ns", avg_ns)
+
+# per-kernel averages of the other runs (rocprofv3 --stats): OUTDIR/other_kernels_stats.csv
+rows = [["run", "kernel", "calls", "avg_us"]]
+for tag in ("unfused", "pipeline", "exact", "pipeline_split16"):
+    for f in glob.glob(os.path.join(out, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in list(csv.reader(fh))[1:]:
+                if "srcnn::" in r[0]:
+                    name = r[0].split("(")[0].replace("void ", "")
+                    rows.append([tag, name, r[1], f"{float(r[3]) / 1000:.1f}"])
+if len(rows) > 1:
+    with open(os.path.join(out, "other_kernels_stats.csv"), "w", newline="") as fh:
+        csv.writer(fh).writerows(rows)

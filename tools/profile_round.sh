@@ -23,6 +23,12 @@ for mode in mfma split16; do
         python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline ) > $OUT/pmc_${mode}_$tag.log 2>&1
   done
 done
+# the other kernels: unfused path (layer-1/2 kernel + layer-3 kernel), pipeline byte kernels, exact kernels
+for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20"; do
+  set -- $cfg; tag=$1; shift
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$tag -o trace -- \
+      python3 $ROOT/bench.py "$@" --warmup 1 --no-cpu-baseline ) > $OUT/trace_$tag.log 2>&1
+done
 tools/measure_all.sh $OUT/measurements.jsonl > /dev/null 2>&1
 python tools/diag_stamps.py > $OUT/diag_stamps_mfma.txt 2>&1
 DIAG_BLOCKS=512 python tools/diag_stamps.py > /dev/null 2>&1
