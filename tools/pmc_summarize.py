@@ -64,7 +64,7 @@ for tag in ("unfused", "pipeline", "exact", "pipeline_split16"):
         with open(f, newline="") as fh:
             for r in list(csv.reader(fh))[1:]:
                 if "srcnn::" in r[0]:
-                    name = r[0].split("(")[0].replace("void ", "")
+                    name = r[0].replace("void ", "").split("(srcnn::StripParams")[0].split("(unsigned char")[0].split("(float")[0]
                     rows.append([tag, name, r[1], f"{float(r[3]) / 1000:.1f}"])
 if len(rows) > 1:
     with open(os.path.join(out, "other_kernels_stats.csv"), "w", newline="") as fh:
