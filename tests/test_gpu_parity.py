@@ -464,3 +464,41 @@ def test_exact_mode_batch_on_device(gpu_ctx, weights_blob):
     for k in range(n):
         r_out, r_pre = oracle.forward_y(frames[k], weights_blob)
         assert np.array_equal(out[k], r_out) and np.array_equal(pre[k], r_pre)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_weights_all_modes(gpu_ctx, weights_blob, seed):
+    """The weight tables are caller data (srcnn_set_weights): random models of the same shape
+    and magnitude go through every packing path -- MFMA fragments (bitwise against the FMA-order
+    model), the exact kernels (bitwise against the reference arithmetic) and the split-f16
+    fragments (tolerance; the mode accepts them because its range check passes)."""
+    rng = np.random.default_rng(seed)
+    blob = weights_blob.copy()
+    blob[64:5248] = rng.normal(0, 0.03, 5184).astype(np.float32)             # W1
+    blob[0:64] = rng.normal(0, 1.0, 64).astype(np.float32)                    # b1
+    blob[5280:7328] = rng.normal(0, 0.08, 2048).astype(np.float32)            # W2
+    blob[5248:5280] = rng.normal(0, 1.0, 32).astype(np.float32)               # b2
+    blob[7329:8129] = rng.normal(0, 0.02, 800).astype(np.float32)             # W3
+    blob[7328] = np.float32(rng.normal(60, 10))                               # b3
+    y = synth_luma(260, 75, frame=seed)
+    r_out, r_pre = oracle.forward_y(y, blob)
+    m_out, m_pre = oracle.gpuorder_forward_y(y, blob)
+    scale = max(1.0, float(np.abs(r_pre).max()) / 255.0)
+    try:
+        gpu_ctx.set_weights_blob(blob)
+        pre = np.empty(y.shape, np.float32)
+        out = gpu_ctx.forward_y(y, preclamp=pre)
+        assert np.array_equal(pre, m_pre) and np.array_equal(out, m_out)
+        assert np.abs(pre - r_pre).max() <= TOL_PRE_ABS * scale
+        gpu_ctx.set_mode(S.MODE_EXACT)
+        e_pre = np.empty(y.shape, np.float32)
+        e_out = gpu_ctx.forward_y(y, preclamp=e_pre)
+        assert np.array_equal(e_pre, r_pre) and np.array_equal(e_out, r_out)
+        gpu_ctx.set_mode(S.MODE_SPLIT16)
+        s_pre = np.empty(y.shape, np.float32)
+        s_out = gpu_ctx.forward_y(y, preclamp=s_pre)
+        assert np.abs(s_pre - r_pre).max() <= TOL_PRE_ABS * scale
+        assert np.abs(s_out.astype(int) - r_out.astype(int)).max() <= 1
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+        gpu_ctx.set_weights_blob(weights_blob)
