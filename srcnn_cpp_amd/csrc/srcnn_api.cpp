@@ -45,6 +45,15 @@ struct srcnn_ctx {
     DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
     // staging for the host-buffer entry points
     DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
+    // seam scratch (srcnn_kernels.h) is written by one launch and read by the seam kernel behind it: one buffer per
+    // stream the context launches on (its own, the two frame lanes, a caller's), so launches on different
+    // streams never share it
+    struct SeamScratch {
+        hipStream_t stream = nullptr;
+        bool used = false;
+        DevBuf buf;
+    };
+    SeamScratch seam_scratch[4];
     // pipeline steps around the conv path
     DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
     int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
@@ -52,9 +61,10 @@ struct srcnn_ctx {
     // explicit work items of single-round launches (build_items): a small cache of device tables, one per
     // launch geometry, so that a caller alternating between a few plane sizes never waits for an upload
     struct ItemTable {
-        int key[6] = {0, 0, 0, 0, 0, 0};
+        int key[7] = {0, 0, 0, 0, 0, 0, 0};
         int count = 0;                  // 0: this geometry uses the regular grid
-        DevBuf dev;
+        int n_seams = 0;
+        DevBuf dev, dev_seams;
         unsigned long stamp = 0;        // last use, for eviction
     };
     static constexpr int kItemTables = 8;
@@ -297,11 +307,20 @@ bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0
 // blocks) (1+skew) tall, the "slow" ones (1-skew) tall, so that all slots are used and the two
 // workgroups of a CU finish together.  Placement only affects speed; the items tile the rows exactly.
 // With ONE workgroup per CU (the pipelined split-f16 kernel) there are n_cu items of plain equal height
-// per strip.  Returns {strip, row_begin, row_end} triples in block order; empty when the geometry does
-// not qualify (the regular grid is used instead).
-std::vector<int> plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2)
+// per strip.  With `want_seams` the boundaries between the items of a strip become seams
+// (srcnn_kernels.h): the items carry the ids of the seams above / below them, `seams` lists
+// {strip, boundary row} per id.  `items` holds ITEM_INTS ints per block in block order; empty when the
+// geometry does not qualify (the regular grid is used instead).
+struct ItemPlan {
+    std::vector<int> items, seams;
+    int count() const { return (int)items.size() / ITEM_INTS; }
+    int n_seams() const { return (int)seams.size() / 2; }
+};
+
+ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
+                    bool want_seams = false)
 {
-    const std::vector<int> none;
+    const ItemPlan none;
     const int rows = row_end - row_begin, slots = wgs_per_cu * n_cu;
     if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu || slots / n_strips < 2 ||
         rows / (slots / n_strips + 1) < 24)
@@ -337,18 +356,29 @@ std::vector<int> plan_items(int n_cu, int n_strips, int row_begin, int row_end, 
     }
     // Block i and block n_cu + i share a CU (measured, tools/diag_stamps.py): pair the tallest fast
     // item with the shortest slow one so that every CU carries the same number of rows.
-    struct Item { int strip, y0, y1; };
+    struct Item { int strip, y0, y1, up, dn; };
+    ItemPlan plan;
+    // a seam needs 4 rows of the item below and leaves 2 rows either side to the seam kernel
+    for (int s = 0; s < n_strips && want_seams; ++s)
+        for (int j = 0; j < k[s]; ++j)
+            if (bounds[s][j + 1] - bounds[s][j] < 2 * SEAM_ROWS) want_seams = false;
     std::vector<Item> fast, slow;
     for (int s = 0; s < n_strips; ++s)
-        for (int j = 0; j < k[s]; ++j)
-            (j < a[s] ? fast : slow).push_back({s, bounds[s][j], bounds[s][j + 1]});
+        for (int j = 0; j < k[s]; ++j) {
+            int up = -1, dn = -1;
+            if (want_seams && j > 0) up = plan.n_seams() - 1;                // made by the item above
+            if (want_seams && j < k[s] - 1) {
+                dn = plan.n_seams();
+                plan.seams.insert(plan.seams.end(), {s, bounds[s][j + 1]});
+            }
+            (j < a[s] ? fast : slow).push_back({s, bounds[s][j], bounds[s][j + 1], up, dn});
+        }
     std::stable_sort(fast.begin(), fast.end(), [](const Item &x, const Item &y) { return x.y1 - x.y0 > y.y1 - y.y0; });
     std::stable_sort(slow.begin(), slow.end(), [](const Item &x, const Item &y) { return x.y1 - x.y0 < y.y1 - y.y0; });
-    std::vector<int> items;
-    items.reserve(3 * (size_t)slots);
-    for (const Item &it : fast) items.insert(items.end(), {it.strip, it.y0, it.y1});
-    for (const Item &it : slow) items.insert(items.end(), {it.strip, it.y0, it.y1});
-    return (int)items.size() == 3 * slots ? items : none;
+    plan.items.reserve(ITEM_INTS * (size_t)slots);
+    for (const Item &it : fast) plan.items.insert(plan.items.end(), {it.strip, it.y0, it.y1, it.up, it.dn});
+    for (const Item &it : slow) plan.items.insert(plan.items.end(), {it.strip, it.y0, it.y1, it.up, it.dn});
+    return plan.count() == slots ? plan : none;
 }
 
 int skew_percent()
@@ -360,33 +390,37 @@ int skew_percent()
 // Device copy of plan_items() for this geometry, from the context's table cache.  *n_items = 0: use the
 // regular grid.  A table is written once, before its first use, into memory no earlier launch reads
 // (a fresh slot, or an evicted one after its last reader has finished), and never modified afterwards.
-int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, int *n_items, const int **d_items)
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
+                const srcnn_ctx::ItemTable **table)
 {
-    *n_items = 0;
-    *d_items = nullptr;
-    const int key[6] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu};
+    *table = nullptr;
+    const int key[7] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu, want_seams ? 1 : 0};
     srcnn_ctx::ItemTable *victim = &c->item_tables[0];
     for (auto &t : c->item_tables) {
         if (t.stamp && std::memcmp(key, t.key, sizeof(key)) == 0) {
             t.stamp = ++c->item_clock;
-            *n_items = t.count;
-            *d_items = static_cast<const int *>(t.dev.p);
+            *table = &t;
             return SRCNN_OK;
         }
         if (t.stamp < victim->stamp) victim = &t;
     }
-    const std::vector<int> items = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu);
-    if (!items.empty()) {
+    const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
+    if (plan.count() > 0) {
         int rc;
         if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());          // evicting: its readers must be done
-        if ((rc = reserve(c, victim->dev, items.size() * sizeof(int)))) return rc;
-        HIP_TRY(c, hipMemcpy(victim->dev.p, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice));
+        if ((rc = reserve(c, victim->dev, plan.items.size() * sizeof(int)))) return rc;
+        HIP_TRY(c, hipMemcpy(victim->dev.p, plan.items.data(), plan.items.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (plan.n_seams() > 0) {
+            if ((rc = reserve(c, victim->dev_seams, plan.seams.size() * sizeof(int)))) return rc;
+            HIP_TRY(c, hipMemcpy(victim->dev_seams.p, plan.seams.data(), plan.seams.size() * sizeof(int),
+                                 hipMemcpyHostToDevice));
+        }
     }
     std::memcpy(victim->key, key, sizeof(key));
-    victim->count = (int)items.size() / 3;
+    victim->count = plan.count();
+    victim->n_seams = plan.n_seams();
     victim->stamp = ++c->item_clock;
-    *n_items = victim->count;
-    *d_items = static_cast<const int *>(victim->dev.p);
+    *table = victim;
     return SRCNN_OK;
 }
 
@@ -415,15 +449,37 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.n_strips = pl.n_strips;
     p.n_segs = pl.n_segs;
     p.items = nullptr;
+    p.seam = nullptr;
     int grid_items = 0;
+    const srcnn_ctx::ItemTable *table = nullptr;
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
     if (mode != MODE_L12 && n_frames == 1) {
-        const int *d_items = nullptr;
-        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, &grid_items, &d_items);
+        // seams instead of halo rows between the items of a strip: float32 fused kernel only
+        static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");     // experiment knob: 0 = halo recompute
+        const bool want_seams = mode == MODE_FUSED && !split16 && !(env_seams && std::atoi(env_seams) == 0) &&
+                                !(p.tune & 2);
+        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, want_seams, &table);
         if (rc) return rc;
+        grid_items = table->count;
         if (grid_items > 0) {
-            p.items = d_items;
+            p.items = static_cast<const int *>(table->dev.p);
+            if (table->n_seams > 0) {
+                srcnn_ctx::SeamScratch *sc = nullptr;
+                for (auto &e : c->seam_scratch)
+                    if (e.used && e.stream == c->stream) sc = &e;
+                for (auto &e : c->seam_scratch)
+                    if (!sc && !e.used) sc = &e;
+                if (!sc) {                  // more streams than slots: wait for everything, start over with slot 0
+                    HIP_TRY(c, hipDeviceSynchronize());
+                    for (auto &e : c->seam_scratch) e.used = false;
+                    sc = &c->seam_scratch[0];
+                }
+                sc->used = true;
+                sc->stream = c->stream;
+                if ((rc = reserve(c, sc->buf, (size_t)table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
+                p.seam = static_cast<float *>(sc->buf.p);
+            }
             p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
             p.n_segs = grid_items;
         }
@@ -439,6 +495,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
+    if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams, static_cast<const int *>(table->dev_seams.p), c->stream));
     return SRCNN_OK;
 }
 
@@ -552,7 +609,11 @@ void srcnn_destroy(srcnn_ctx *c)
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
                       &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16})
         release(*b);
-    for (auto &t : c->item_tables) release(t.dev);
+    for (auto &sc : c->seam_scratch) release(sc.buf);
+    for (auto &t : c->item_tables) {
+        release(t.dev);
+        release(t.dev_seams);
+    }
     for (int k = 0; k < 2; ++k) {
         release(c->lane_in[k]);
         release(c->lane_out[k]);
@@ -624,11 +685,11 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
     if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
-        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu);
+        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu).items;
         if (!items.empty()) {
-            out[0] = (int)items.size() / 3;
+            out[0] = (int)items.size() / ITEM_INTS;
             out[1] = 0;
-            for (size_t i = 0; i < items.size(); i += 3) out[1] = std::max(out[1], items[i + 2] - items[i + 1]);
+            for (size_t i = 0; i < items.size(); i += ITEM_INTS) out[1] = std::max(out[1], items[i + 2] - items[i + 1]);
             out[3] = (out[0] + pl.n_strips - 1) / pl.n_strips;
         }
     }

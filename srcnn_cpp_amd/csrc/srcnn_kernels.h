@@ -79,12 +79,23 @@ struct StripParams {
     int width, height;              // full image (border-replication domain)
     int row_begin, row_end;         // output rows produced by this launch
     int seg_rows, n_strips, n_segs; // workgroup decomposition
-    const int *items;               // optional explicit work items {strip, row_begin, row_end} per block
-                                    // (single-round launches, see build_items()); nullptr = regular grid
+    const int *items;               // optional explicit work items, ITEM_INTS ints per block: {strip, row_begin,
+                                    // row_end, seam above, seam below} (see plan_items()); nullptr = regular grid
+    float *seam;                    // seam scratch, SEAM_FLOATS * NTHREADS floats per seam (MODE_FUSED, items only)
     int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
 };
 
+// A SEAM is the boundary between two vertically adjacent work items of a strip.  Instead of recomputing the
+// two feature rows either side of it (4 rows per item), the item above hands over its 12 vertical-chain
+// registers and the item below the tap partials of its first 4 rows (15 each); srcnn_seam_kernel replays those
+// 4 chain steps and finishes the 4 output rows around the seam -- same operations in the same order, so the
+// result is bit-identical to the halo-recompute form.
+constexpr int ITEM_INTS = 5;
+constexpr int SEAM_R = 12, SEAM_T = 15, SEAM_ROWS = 4;
+constexpr int SEAM_FLOATS = SEAM_R + SEAM_ROWS * SEAM_T;      // per thread
+
 size_t strip_lds_bytes(int mode);
+hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, hipStream_t stream);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 
 size_t split16_lds_bytes();

@@ -94,17 +94,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     // 12 halo columns / rows of Y -- instead of every 8th one.  Bijective for any grid size; speed
     // only (the input is 1 B/pixel, so the effect on this MFMA-bound kernel is within noise).
     int bid = blockIdx.x;
-    int strip, frame = 0, ys, ye;
+    int strip, frame = 0, ys, ye, seam_up = -1, seam_dn = -1;
     if (p.items) {
         // Single-round launch: the host hands every block its own {strip, row range}.  Block ids are
         // the hardware dispatch order -- the first n_cu blocks take wave slot 0 of every CU and win the
         // age-based MFMA arbitration, so they run ~12 % faster than the block that joins them later --
         // and the host sizes the items accordingly (measured dispatch order, profiles/r01; speed only:
         // any placement computes the same plane).
-        const int *it = p.items + 3 * bid;
+        const int *it = p.items + ITEM_INTS * bid;
         strip = it[0];
         ys = it[1];
         ye = it[2];
+        if constexpr (MODE == MODE_FUSED) {
+            seam_up = it[3];
+            seam_dn = it[4];
+        }
     } else {
         if (!(p.tune & 8)) {
             const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -120,8 +124,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 
     const int xs = strip * OWM;        // first output column of the strip
     const int gx0 = xs - HALO;         // image column of feature column xi = 0
-    const int f_lo = max(ys - HALO, 0);
-    const int f_hi = min(ye + HALO, H);   // feature rows [f_lo, f_hi) are computed
+    // A seam (srcnn_kernels.h) replaces the two halo feature rows on that side: the item then computes only its
+    // own rows and leaves the two output rows next to the seam to srcnn_seam_kernel.
+    const bool top_open = seam_up >= 0, bot_open = seam_dn >= 0;
+    const int f_lo = top_open ? ys : max(ys - HALO, 0);
+    const int f_hi = bot_open ? ye : min(ye + HALO, H);   // feature rows [f_lo, f_hi) are computed
+    const int out_lo = top_open ? ys + 2 : ys, out_hi = bot_open ? ye - 2 : ye;   // output rows finished here
 
     // ---- weight fragments -> registers (A operands, one VGPR per k-step) ----
     const float *wf = p.wfrag + lane;
@@ -227,6 +235,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     // After the layer-3 MFMAs of feature row f: advance the chains, emit the finished F values.
     auto vertical = [&](int f, const f32x16 &t) {
         const int fplane = 3 * half * FW + xi;              // half 0 -> planes 0..2, half 1 -> planes 3..5
+        if (top_open && f < ys + SEAM_ROWS) {
+            // hand the tap partials of the item's first rows to the seam above (4 times per item)
+            float *o = p.seam + ((long)seam_up * SEAM_FLOATS + SEAM_R + (f - ys) * SEAM_T) * NTHREADS + tid;
+#pragma unroll
+            for (int k = 0; k < SEAM_T; ++k) o[k * NTHREADS] = t[k];
+        }
         if (f > 0) {
             float *fo = ftile(f, 0) + fplane;
 #pragma unroll
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 #pragma unroll
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;
-        finalize(y, acc, px_ok && (y >= ys) && (y < ye));
+        finalize(y, acc, px_ok && (y >= out_lo) && (y < out_hi));
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -407,6 +421,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             dg_bar += e - dg_d;
         }
     }
+    if (bot_open) {
+        // hand the vertical chains (taps of this item's last rows) to the seam below
+        float *o = p.seam + (long)seam_dn * SEAM_FLOATS * NTHREADS + tid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) o[(k * 3 + s) * NTHREADS] = R[k][s];
+    }
     if constexpr (DIAG) {
         const unsigned long long t1 = stamp();
         const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -424,6 +446,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);  // XCC_ID
         }
     }
+}
+
+// Finishes the four output rows around every seam: replays the four chain steps the lower item's first rows
+// would have contributed to the upper item's chains (same adds in the same order as vertical() / hp_use() of
+// srcnn_strip_kernel), then the horizontal 5-term sum, bias, truncate, clamp (src/srcnn.cpp:235-240).
+// One workgroup per seam, thread <-> (wave, lane) as in the strip kernel.
+template <bool PRE>
+__global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams p, const int *__restrict__ seams)
+{
+    __shared__ float ft[SEAM_ROWS][6][FW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
+    constexpr int HALO = 2, OWM = FW - 2 * HALO;
+    const int strip = seams[2 * blockIdx.x], b = seams[2 * blockIdx.x + 1];
+    const int W = p.width;
+    const int gx0 = strip * OWM - HALO, xi = 32 * wave + j, gx = gx0 + xi;
+    const float *sc = p.seam + (long)blockIdx.x * SEAM_FLOATS * NTHREADS + tid;
+    float R[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) R[k][s] = sc[(k * 3 + s) * NTHREADS];
+#pragma unroll
+    for (int r = 0; r < SEAM_ROWS; ++r) {
+        float t[SEAM_T];
+#pragma unroll
+        for (int k = 0; k < SEAM_T; ++k) t[k] = sc[(SEAM_R + r * SEAM_T + k) * NTHREADS];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            ft[r][3 * half + s][xi] = R[3][s] + t[5 * s + 4];
+            R[3][s] = R[2][s] + t[5 * s + 3];
+            R[2][s] = R[1][s] + t[5 * s + 2];
+            R[1][s] = R[0][s] + t[5 * s + 1];
+            R[0][s] = t[5 * s];
+        }
+    }
+    __syncthreads();
+    if (xi < HALO || xi >= FW - HALO || gx >= W) return;
+    int xn[5];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+#pragma unroll
+    for (int r = 0; r < SEAM_ROWS; ++r) {
+        float acc = ft[r][0][xn[0]];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) acc += ft[r][n][xn[n]];
+        const float v = acc + p.b3;
+        const long o = (long)(b - 2 + r - p.dst_row0) * p.dst_stride + gx;
+        p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
+        if constexpr (PRE) p.pre[o] = v;
+    }
+}
+
+hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, hipStream_t stream)
+{
+    if (p.pre) hipLaunchKernelGGL((srcnn_seam_kernel<true>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
+    else hipLaunchKernelGGL((srcnn_seam_kernel<false>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
+    return hipGetLastError();
 }
 
 size_t strip_lds_bytes(int /*mode*/)

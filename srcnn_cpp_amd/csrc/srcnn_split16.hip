@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
     int bid = blockIdx.x;
     int strip, frame = 0, ys, ye;
     if (p.items) {
-        const int *it = p.items + 3 * bid;
+        const int *it = p.items + ITEM_INTS * bid;
         strip = it[0];
         ys = it[1];
         ye = it[2];
