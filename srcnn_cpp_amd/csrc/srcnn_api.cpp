@@ -322,8 +322,11 @@ ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew
 {
     const ItemPlan none;
     const int rows = row_end - row_begin, slots = wgs_per_cu * n_cu;
+    // shortest useful item: with halo rows to recompute (4 per item) short items do not pay; with seams an item
+    // only has to be tall enough for the hand-over (2 * SEAM_ROWS, 10 for some slack in the skewed heights)
+    const int min_rows = want_seams ? 10 : 24;
     if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu || slots / n_strips < 2 ||
-        rows / (slots / n_strips + 1) < 24)
+        rows / (slots / n_strips + 1) < min_rows)
         return none;
     if (wgs_per_cu == 1) skew_pct = 0;
     const int kbase = slots / n_strips, kextra = slots % n_strips;      // strips [0,kextra) get kbase+1 items
@@ -685,7 +688,8 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
     if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
-        const std::vector<int> items = plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu).items;
+        const std::vector<int> items =
+            plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu, c->mode == SRCNN_MODE_MFMA).items;
         if (!items.empty()) {
             out[0] = (int)items.size() / ITEM_INTS;
             out[1] = 0;
