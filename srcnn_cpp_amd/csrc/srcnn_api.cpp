@@ -51,7 +51,7 @@ struct srcnn_ctx {
     struct SeamScratch {
         hipStream_t stream = nullptr;
         bool used = false;
-        DevBuf buf;
+        DevBuf buf, cbuf;           // row seams, column seams
     };
     SeamScratch seam_scratch[4];
     // pipeline steps around the conv path
@@ -272,9 +272,9 @@ struct Plan {
 // rows per segment) and fewer workgroup start-ups (weight fragments, 9-row Y prologue: worth about
 // STARTUP_ROWS rows), more segments fill the 2-workgroups-per-CU slots more evenly.  Everything is
 // regular, so scan.
-Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, int wgs_per_cu = 2)
+Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, int wgs_per_cu = 2, int col_halo = -1)
 {
-    const int ow = FW - 2 * halo;
+    const int ow = FW - 2 * (col_halo < 0 ? halo : col_halo);
     Plan best{rows, (width + ow - 1) / ow, 1};
     const long slots = (long)wgs_per_cu * c->n_cu;
     double best_eff = -1.0;
@@ -453,21 +453,34 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.n_segs = pl.n_segs;
     p.items = nullptr;
     p.seam = nullptr;
+    p.cseam = nullptr;
+    p.strips_total = pl.n_strips;
     int grid_items = 0;
     const srcnn_ctx::ItemTable *table = nullptr;
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
     if (mode != MODE_L12 && n_frames == 1) {
-        // seams instead of halo rows between the items of a strip: float32 fused kernel only
-        static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");     // experiment knob: 0 = halo recompute
-        const bool want_seams = mode == MODE_FUSED && !split16 && !(env_seams && std::atoi(env_seams) == 0) &&
-                                !(p.tune & 2);
-        int rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, want_seams, &table);
-        if (rc) return rc;
+        // float32 fused kernel only: seams instead of halo rows between the items of a strip, and column seams
+        // instead of halo columns between strips (srcnn_kernels.h).  SRCNN_DEBUG_SEAMS: 0 = neither, 1 = rows only.
+        static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
+        const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
+        const bool want_seams = mode == MODE_FUSED && !split16 && (seam_knob & 1) && !(p.tune & 2);
+        int rc;
+        if (want_seams && (seam_knob & 2)) {
+            // strips of FW output columns; the last strip must hold the 4 columns its left neighbour's pixels need
+            const int ns_cs = (p.width + FW - 1) / FW;
+            if (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1) {
+                if ((rc = build_items(c, ns_cs, p.row_begin, p.row_end, wgs_per_cu, true, &table))) return rc;
+                if (table->count > 0) p.strips_total = ns_cs;
+                else table = nullptr;
+            }
+        }
+        const bool col_seams = table != nullptr;
+        if (!table && (rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, want_seams, &table))) return rc;
         grid_items = table->count;
         if (grid_items > 0) {
             p.items = static_cast<const int *>(table->dev.p);
-            if (table->n_seams > 0) {
+            if (table->n_seams > 0 || col_seams) {
                 srcnn_ctx::SeamScratch *sc = nullptr;
                 for (auto &e : c->seam_scratch)
                     if (e.used && e.stream == c->stream) sc = &e;
@@ -480,8 +493,15 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
                 }
                 sc->used = true;
                 sc->stream = c->stream;
-                if ((rc = reserve(c, sc->buf, (size_t)table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
-                p.seam = static_cast<float *>(sc->buf.p);
+                if (table->n_seams > 0) {
+                    if ((rc = reserve(c, sc->buf, (size_t)table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
+                    p.seam = static_cast<float *>(sc->buf.p);
+                }
+                if (col_seams) {
+                    const size_t n = (size_t)p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
+                    if ((rc = reserve(c, sc->cbuf, n))) return rc;
+                    p.cseam = static_cast<float *>(sc->cbuf.p);
+                }
             }
             p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
             p.n_segs = grid_items;
@@ -499,6 +519,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams, static_cast<const int *>(table->dev_seams.p), c->stream));
+    if (p.cseam) HIP_TRY(c, launch_cseams(p, c->stream));
     return SRCNN_OK;
 }
 
@@ -612,7 +633,10 @@ void srcnn_destroy(srcnn_ctx *c)
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
                       &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16})
         release(*b);
-    for (auto &sc : c->seam_scratch) release(sc.buf);
+    for (auto &sc : c->seam_scratch) {
+        release(sc.buf);
+        release(sc.cbuf);
+    }
     for (auto &t : c->item_tables) {
         release(t.dev);
         release(t.dev_seams);

@@ -72,6 +72,46 @@ __device__ __forceinline__ float relu(float x)
     return r;
 }
 
+// Column-seam export slot e of a strip, for one output row: the sum, in this order, of up to four F-tile
+// entries (plane n, strip column c).  Slots 0-4 belong to the right edge (0, 1: the own terms of the pixels at
+// columns 126 and 127, i.e. their 5-term sums cut off where the right neighbour's columns begin; 2-4: single
+// values the right neighbour's first two pixels start with), slots 5-14 to the left edge (5-7, 8-11: the own
+// terms of the pixels at columns 0 and 1, added one by one behind the left neighbour's; 12-14: single values
+// that finish the left neighbour's last two pixels).  See srcnn_cseam_kernel.
+__device__ const signed char CSEAM_TERMS[15][9] = {
+    {4, 0, 124, 1, 125, 2, 126, 3, 127}, {3, 0, 125, 1, 126, 2, 127, 0, 0}, {1, 0, 126, 0, 0, 0, 0, 0, 0},
+    {1, 0, 127, 0, 0, 0, 0, 0, 0},       {1, 1, 127, 0, 0, 0, 0, 0, 0},     {1, 2, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 1, 0, 0, 0, 0, 0, 0},         {1, 4, 2, 0, 0, 0, 0, 0, 0},       {1, 1, 0, 0, 0, 0, 0, 0, 0},
+    {1, 2, 1, 0, 0, 0, 0, 0, 0},         {1, 3, 2, 0, 0, 0, 0, 0, 0},       {1, 4, 3, 0, 0, 0, 0, 0, 0},
+    {1, 3, 0, 0, 0, 0, 0, 0, 0},         {1, 4, 0, 0, 0, 0, 0, 0, 0},       {1, 4, 1, 0, 0, 0, 0, 0, 0}};
+
+// Export slot of lane e (e < 15 exports): term count and the tile offsets n * FW + c of its up to four terms,
+// fetched once per kernel; cseam_export() then costs four LDS reads, three selects/adds and one store per row.
+struct CseamLane {
+    int cnt, off[4];
+};
+__device__ __forceinline__ CseamLane cseam_lane(int e)
+{
+    CseamLane cl = {0, {0, 0, 0, 0}};
+    if (e < 15) {
+        const signed char *t = CSEAM_TERMS[e];
+        cl.cnt = t[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cl.off[i] = i < t[0] ? t[1 + 2 * i] * FW + t[2 + 2 * i] : 0;
+    }
+    return cl;
+}
+// Export the values of one finished F-tile row (planes at tile[n * FW + c]); all lanes of one wave call it.
+__device__ __forceinline__ void cseam_export(const float *tile, float *dst, int e, const CseamLane &cl)
+{
+    const float a = tile[cl.off[0]], b = tile[cl.off[1]], c = tile[cl.off[2]], d = tile[cl.off[3]];
+    float v = a;
+    v = cl.cnt > 1 ? v + b : v;
+    v = cl.cnt > 2 ? v + c : v;
+    v = cl.cnt > 3 ? v + d : v;
+    if (cl.cnt > 0) dst[e] = v;
+}
+
 template <int MODE, bool PRE, bool DIAG = false>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
 {
@@ -86,7 +126,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     const int half = lane >> 5;   // which of the 2 k-slots this lane feeds
 
     constexpr int HALO = (MODE == MODE_L12) ? 0 : 2;   // layer-3 radius
-    constexpr int OWM = FW - 2 * HALO;                 // output columns per strip
 
     const int W = p.width, H = p.height;
     // XCD-aware work mapping: workgroups with equal blockIdx % 8 share an XCD (and its L2), so hand
@@ -122,8 +161,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         ye = min(ys + p.seg_rows, p.row_end);
     }
 
-    const int xs = strip * OWM;        // first output column of the strip
-    const int gx0 = xs - HALO;         // image column of feature column xi = 0
+    // column seams (srcnn_kernels.h): the strip outputs all FW columns, its four edge pixels are finished elsewhere
+    const bool cs = (MODE == MODE_FUSED) && p.cseam != nullptr;
+    const CseamLane cl = cseam_lane((cs && threadIdx.x < 15) ? (int)threadIdx.x : 15);
+    const int halo_c = cs ? 0 : HALO;
+    const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
+    const int gx0 = xs - halo_c;                // image column of feature column xi = 0
     // A seam (srcnn_kernels.h) replaces the two halo feature rows on that side: the item then computes only its
     // own rows and leaves the two output rows next to the seam to srcnn_seam_kernel.
     const bool top_open = seam_up >= 0, bot_open = seam_dn >= 0;
@@ -214,7 +257,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     if constexpr (MODE != MODE_L12) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
-        px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+        px_ok = cs ? (gx < W) && (xi >= 2 || strip == 0) && (xi < FW - 2 || strip == p.strips_total - 1)
+                   : (xi >= HALO) && (xi < FW - HALO) && (gx < W);
     }
     float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     auto finalize = [&](int y, float acc, bool ok) {
@@ -288,6 +332,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;
         finalize(y, acc, px_ok && (y >= out_lo) && (y < out_hi));
+        if (cs && wave == 0 && (y >= out_lo) && (y < out_hi))
+            cseam_export(ftile(g, slot), p.cseam + ((long)strip * (p.row_end - p.row_begin) + (y - p.row_begin)) * CSEAM_FLOATS, lane, cl);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -457,10 +503,12 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
 {
     __shared__ float ft[SEAM_ROWS][6][FW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
-    constexpr int HALO = 2, OWM = FW - 2 * HALO;
+    constexpr int HALO = 2;
     const int strip = seams[2 * blockIdx.x], b = seams[2 * blockIdx.x + 1];
     const int W = p.width;
-    const int gx0 = strip * OWM - HALO, xi = 32 * wave + j, gx = gx0 + xi;
+    const bool cs = p.cseam != nullptr;
+    const int halo_c = cs ? 0 : HALO;
+    const int gx0 = strip * (FW - 2 * halo_c) - halo_c, xi = 32 * wave + j, gx = gx0 + xi;
     const float *sc = p.seam + (long)blockIdx.x * SEAM_FLOATS * NTHREADS + tid;
     float R[4][3];
 #pragma unroll
@@ -482,7 +530,14 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
         }
     }
     __syncthreads();
-    if (xi < HALO || xi >= FW - HALO || gx >= W) return;
+    if (cs && wave == 0) {
+        const CseamLane cl = cseam_lane(lane);
+        for (int r = 0; r < SEAM_ROWS; ++r)
+            cseam_export(&ft[r][0][0], p.cseam + ((long)strip * (p.row_end - p.row_begin) + (b - 2 + r - p.row_begin)) * CSEAM_FLOATS, lane, cl);
+    }
+    const bool px_ok = cs ? (gx < W) && (xi >= 2 || strip == 0) && (xi < FW - 2 || strip == p.strips_total - 1)
+                          : (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+    if (!px_ok) return;
     int xn[5];
 #pragma unroll
     for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
@@ -496,6 +551,44 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
         p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (PRE) p.pre[o] = v;
     }
+}
+
+// The four output pixels around every strip boundary, every row of the launch: columns xT-2, xT-1 of the left
+// strip S (its pixels 126, 127) and xT, xT+1 of the right strip T (its pixels 0, 1), from the two strips' exports
+// (CSEAM_TERMS), added in the order of hp_use(): F0 + F1 + F2 + F3 + F4, then the bias, truncate, clamp.
+template <bool PRE>
+__global__ __launch_bounds__(256) void srcnn_cseam_kernel(const StripParams p)
+{
+    const int rows = p.row_end - p.row_begin;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int v = (int)(idx / rows), yrel = (int)(idx - (long)v * rows);
+    if (v >= p.strips_total - 1) return;
+    const float *es = p.cseam + ((long)v * rows + yrel) * CSEAM_FLOATS;
+    const float *et = p.cseam + ((long)(v + 1) * rows + yrel) * CSEAM_FLOATS;
+    const int xt = (v + 1) * FW;
+    float acc[4];
+    acc[0] = es[0] + et[13];
+    acc[1] = (es[1] + et[12]) + et[14];
+    acc[2] = (((es[2] + es[4]) + et[5]) + et[6]) + et[7];
+    acc[3] = (((es[3] + et[8]) + et[9]) + et[10]) + et[11];
+    const long o = (long)(p.row_begin + yrel - p.dst_row0) * p.dst_stride + xt - 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (xt - 2 + k >= p.width) break;
+        const float val = acc[k] + p.b3;
+        p.dst[o + k] = (uint8_t)clampi((int)val, 0, 255);
+        if constexpr (PRE) p.pre[o + k] = val;
+    }
+}
+
+hipError_t launch_cseams(const StripParams &p, hipStream_t stream)
+{
+    const long n = (long)(p.strips_total - 1) * (p.row_end - p.row_begin);
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (p.pre) hipLaunchKernelGGL((srcnn_cseam_kernel<true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((srcnn_cseam_kernel<false>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, hipStream_t stream)
