@@ -507,6 +507,35 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
             p.n_segs = grid_items;
         }
     }
+    // Batches (regular grid): column seams only -- the planner already makes the segments tall, and a row seam
+    // costs 74 KB of scratch.
+    if (mode == MODE_FUSED && !split16 && n_frames > 1 && !(p.tune & 2)) {
+        static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
+        const int ns_cs = (p.width + FW - 1) / FW;
+        if ((!env_seams || (std::atoi(env_seams) & 2)) && (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1)) {
+            pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo, wgs_per_cu, 0);
+            p.seg_rows = pl.seg_rows;
+            p.n_strips = pl.n_strips;
+            p.n_segs = pl.n_segs;
+            p.strips_total = pl.n_strips;
+            srcnn_ctx::SeamScratch *sc = nullptr;
+            for (auto &e : c->seam_scratch)
+                if (e.used && e.stream == c->stream) sc = &e;
+            for (auto &e : c->seam_scratch)
+                if (!sc && !e.used) sc = &e;
+            if (!sc) {
+                HIP_TRY(c, hipDeviceSynchronize());
+                for (auto &e : c->seam_scratch) e.used = false;
+                sc = &c->seam_scratch[0];
+            }
+            sc->used = true;
+            sc->stream = c->stream;
+            const size_t n = (size_t)n_frames * p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
+            int rc;
+            if ((rc = reserve(c, sc->cbuf, n))) return rc;
+            p.cseam = static_cast<float *>(sc->cbuf.p);
+        }
+    }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
     p.wfrag16 = static_cast<const uint32_t *>(c->wfrag16.p);
     p.sink = static_cast<float *>(c->sink.p);
@@ -519,7 +548,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams, static_cast<const int *>(table->dev_seams.p), c->stream));
-    if (p.cseam) HIP_TRY(c, launch_cseams(p, c->stream));
+    if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     return SRCNN_OK;
 }
 
@@ -705,15 +734,25 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
 {
     if (!c || !out || width <= 0 || height <= 0 || n_frames <= 0) return SRCNN_ERR_INVALID;
     static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
+    static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
     const int wgs_per_cu = split16_wgs_per_cu(c->mode == SRCNN_MODE_SPLIT16, env_tune ? std::atoi(env_tune) : 0);
-    const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu);
+    // mirrors run_strip(): the float32 fused kernel uses column seams (strips of FW columns) when the geometry allows
+    const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
+    const int ns_cs = (width + FW - 1) / FW;
+    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (n_frames > 1 || (seam_knob & 1)) &&
+                     (width - (ns_cs - 1) * FW >= 4 || ns_cs == 1);
+    if (col_seams && n_frames == 1 &&
+        plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), wgs_per_cu, true).items.empty())
+        col_seams = false;
+    const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu, col_seams ? 0 : -1);
     out[0] = pl.n_strips * pl.n_segs * n_frames;
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
     if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
         const std::vector<int> items =
-            plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu, c->mode == SRCNN_MODE_MFMA).items;
+            plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu,
+                       c->mode == SRCNN_MODE_MFMA && (seam_knob & 1)).items;
         if (!items.empty()) {
             out[0] = (int)items.size() / ITEM_INTS;
             out[1] = 0;

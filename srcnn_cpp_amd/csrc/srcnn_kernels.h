@@ -82,7 +82,7 @@ struct StripParams {
     const int *items;               // optional explicit work items, ITEM_INTS ints per block: {strip, row_begin,
                                     // row_end, seam above, seam below} (see plan_items()); nullptr = regular grid
     float *seam;                    // seam scratch, SEAM_FLOATS * NTHREADS floats per seam (MODE_FUSED, items only)
-    float *cseam;                   // column-seam scratch [strip][row][CSEAM_FLOATS]; non-null = strips without column halo
+    float *cseam;                   // column-seam scratch [frame][strip][row][CSEAM_FLOATS]; non-null = strips without column halo
     int strips_total;               // number of strips of the plane (n_strips is 1 in an items launch)
     int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
 };
@@ -105,7 +105,7 @@ hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, h
 // (cseam_terms(): partial 5-term sums in the original order, or single F_n values) and srcnn_cseam_kernel
 // completes those pixels -- same additions in the same order, bit-identical.
 constexpr int CSEAM_FLOATS = 16;      // 15 used
-hipError_t launch_cseams(const StripParams &p, hipStream_t stream);
+hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 
 size_t split16_lds_bytes();

@@ -333,7 +333,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         const int y = g - 2 + slot;
         finalize(y, acc, px_ok && (y >= out_lo) && (y < out_hi));
         if (cs && wave == 0 && (y >= out_lo) && (y < out_hi))
-            cseam_export(ftile(g, slot), p.cseam + ((long)strip * (p.row_end - p.row_begin) + (y - p.row_begin)) * CSEAM_FLOATS, lane, cl);
+            cseam_export(ftile(g, slot),
+                         p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) + (y - p.row_begin)) * CSEAM_FLOATS,
+                         lane, cl);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -559,19 +561,19 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
 template <bool PRE>
 __global__ __launch_bounds__(256) void srcnn_cseam_kernel(const StripParams p)
 {
-    const int rows = p.row_end - p.row_begin;
+    const int rows = p.row_end - p.row_begin, frame = blockIdx.y;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int v = (int)(idx / rows), yrel = (int)(idx - (long)v * rows);
     if (v >= p.strips_total - 1) return;
-    const float *es = p.cseam + ((long)v * rows + yrel) * CSEAM_FLOATS;
-    const float *et = p.cseam + ((long)(v + 1) * rows + yrel) * CSEAM_FLOATS;
+    const float *es = p.cseam + (((long)frame * p.strips_total + v) * rows + yrel) * CSEAM_FLOATS;
+    const float *et = es + (long)rows * CSEAM_FLOATS;
     const int xt = (v + 1) * FW;
     float acc[4];
     acc[0] = es[0] + et[13];
     acc[1] = (es[1] + et[12]) + et[14];
     acc[2] = (((es[2] + es[4]) + et[5]) + et[6]) + et[7];
     acc[3] = (((es[3] + et[8]) + et[9]) + et[10]) + et[11];
-    const long o = (long)(p.row_begin + yrel - p.dst_row0) * p.dst_stride + xt - 2;
+    const long o = (long)frame * p.dst_frame_pitch + (long)(p.row_begin + yrel - p.dst_row0) * p.dst_stride + xt - 2;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (xt - 2 + k >= p.width) break;
@@ -581,11 +583,11 @@ __global__ __launch_bounds__(256) void srcnn_cseam_kernel(const StripParams p)
     }
 }
 
-hipError_t launch_cseams(const StripParams &p, hipStream_t stream)
+hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
 {
     const long n = (long)(p.strips_total - 1) * (p.row_end - p.row_begin);
     if (n <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n + 255) / 256));
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_frames);
     if (p.pre) hipLaunchKernelGGL((srcnn_cseam_kernel<true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((srcnn_cseam_kernel<false>), grid, dim3(256), 0, stream, p);
     return hipGetLastError();
