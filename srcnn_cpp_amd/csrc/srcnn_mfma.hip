@@ -167,6 +167,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     const int halo_c = cs ? 0 : HALO;
     const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
     const int gx0 = xs - halo_c;                // image column of feature column xi = 0
+    // wave 0 exports: address of this lane's slot for output row 0 of the plane (null in the other waves; taking
+    // turns among the four waves measured no better)
+    float *cs_row0 = (cs && wave == 0)
+                         ? p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) - p.row_begin) * CSEAM_FLOATS + lane
+                         : nullptr;
     // A seam (srcnn_kernels.h) replaces the two halo feature rows on that side: the item then computes only its
     // own rows and leaves the two output rows next to the seam to srcnn_seam_kernel.
     const bool top_open = seam_up >= 0, bot_open = seam_dn >= 0;
@@ -332,10 +337,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;
         finalize(y, acc, px_ok && (y >= out_lo) && (y < out_hi));
-        if (cs && wave == 0 && (y >= out_lo) && (y < out_hi))
-            cseam_export(ftile(g, slot),
-                         p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) + (y - p.row_begin)) * CSEAM_FLOATS,
-                         lane, cl);
+        if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, 0, cl);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that

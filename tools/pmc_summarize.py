@@ -12,9 +12,14 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KERNEL = {"mfma": "srcnn_strip_kernel", "split16": "srcnn_split16_kernel"}
-for mode, kname in KERNEL.items():
+# kernels of one step: the strip kernel does the work; with seams (float32 mode) two small kernels finish the
+# rows / columns at item and strip boundaries -- their HBM bytes belong to the step's traffic
+KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seam_kernel", "srcnn_cseam_kernel"], "split16": ["srcnn_split16_kernel"]}
+for mode, knames in KERNEL.items():
+    kname = knames[0]
     sums, cnt = defaultdict(float), defaultdict(int)
+    extra = defaultdict(lambda: defaultdict(float))
+    extra_cnt = defaultdict(lambda: defaultdict(int))
     grid = None
     for f in glob.glob(os.path.join(out, f"pmc_{mode}_*", "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
@@ -23,6 +28,10 @@ for mode, kname in KERNEL.items():
                     sums[row["Counter_Name"]] += float(row["Counter_Value"])
                     cnt[row["Counter_Name"]] += 1
                     grid = int(row["Grid_Size"]) // int(row["Workgroup_Size"])
+                for k2 in knames[1:]:
+                    if k2 in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                        extra[k2][row["Counter_Name"]] += float(row["Counter_Value"])
+                        extra_cnt[k2][row["Counter_Name"]] += 1
     if not sums:
         continue
     mean = {k: sums[k] / cnt[k] for k in sums}
@@ -31,6 +40,13 @@ for mode, kname in KERNEL.items():
         d["hbm_read_bytes"] = mean["FETCH_SIZE"] * 1024 * 2
         d["hbm_write_bytes"] = mean["WRITE_SIZE"] * 1024
         d["hbm_bytes"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
+        d["hbm_bytes_step"] = d["hbm_bytes"]
+        for k2 in knames[1:]:
+            if extra[k2]:
+                # dword loads / byte stores of the seam kernels: FETCH_SIZE and WRITE_SIZE both exact (pmc_calibration.txt)
+                b = sum(extra[k2][c] / extra_cnt[k2][c] for c in extra[k2]) * 1024
+                d[f"hbm_bytes_{k2}"] = b
+                d["hbm_bytes_step"] += b
     if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
         d["mfma_busy_frac_of_simd_cycles"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (mean["GRBM_GUI_ACTIVE"] / 8)
     if "SQ_INSTS_MFMA" in mean:
