@@ -89,12 +89,14 @@ struct StripParams {
 
 // A SEAM is the boundary between two vertically adjacent work items of a strip.  Instead of recomputing the
 // two feature rows either side of it (4 rows per item), the item above hands over its 12 vertical-chain
-// registers and the item below the tap partials of its first 4 rows (15 each); srcnn_seam_kernel replays those
-// 4 chain steps and finishes the 4 output rows around the seam -- same operations in the same order, so the
-// result is bit-identical to the halo-recompute form.
+// registers and the item below the tap partials of its first 4 rows that those chains still need (tap rows
+// m > r of row r: 12 + 9 + 6 + 3 values); srcnn_seam_kernel replays those chain steps and finishes the 4 output
+// rows around the seam -- same operations in the same order, so the result is bit-identical to the
+// halo-recompute form.
 constexpr int ITEM_INTS = 5;
-constexpr int SEAM_R = 12, SEAM_T = 15, SEAM_ROWS = 4;
-constexpr int SEAM_FLOATS = SEAM_R + SEAM_ROWS * SEAM_T;      // per thread
+constexpr int SEAM_R = 12, SEAM_ROWS = 4;
+__host__ __device__ constexpr int seam_t_off(int r) { return SEAM_R + 3 * (r * 4 - r * (r - 1) / 2); }   // 12, 24, 33, 39
+constexpr int SEAM_FLOATS = SEAM_R + 3 * (4 + 3 + 2 + 1);     // 42 per thread
 
 size_t strip_lds_bytes(int mode);
 hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, hipStream_t stream);

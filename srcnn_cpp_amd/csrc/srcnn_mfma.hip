@@ -285,10 +285,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     auto vertical = [&](int f, const f32x16 &t) {
         const int fplane = 3 * half * FW + xi;              // half 0 -> planes 0..2, half 1 -> planes 3..5
         if (top_open && f < ys + SEAM_ROWS) {
-            // hand the tap partials of the item's first rows to the seam above (4 times per item)
-            float *o = p.seam + ((long)seam_up * SEAM_FLOATS + SEAM_R + (f - ys) * SEAM_T) * NTHREADS + tid;
+            // hand the tap partials the chains of the seam above still need to it (4 times per item):
+            // row r = f - ys contributes its tap rows m = r+1 .. 4
+            const int r = f - ys;
+            float *o = p.seam + ((long)seam_up * SEAM_FLOATS + seam_t_off(r)) * NTHREADS + tid;
 #pragma unroll
-            for (int k = 0; k < SEAM_T; ++k) o[k * NTHREADS] = t[k];
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int m = 1; m < 5; ++m)
+                    if (m > r) o[(s * (4 - r) + (m - r - 1)) * NTHREADS] = t[5 * s + m];
         }
         if (f > 0) {
             float *fo = ftile(f, 0) + fplane;
@@ -521,16 +526,18 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
         for (int s = 0; s < 3; ++s) R[k][s] = sc[(k * 3 + s) * NTHREADS];
 #pragma unroll
     for (int r = 0; r < SEAM_ROWS; ++r) {
-        float t[SEAM_T];
+        // tap rows m = r+1 .. 4 of the lower item's row r (the others feed output rows below the seam's four)
+        float t[3][5];
 #pragma unroll
-        for (int k = 0; k < SEAM_T; ++k) t[k] = sc[(SEAM_R + r * SEAM_T + k) * NTHREADS];
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int m = r + 1; m < 5; ++m) t[s][m] = sc[(seam_t_off(r) + s * (4 - r) + (m - r - 1)) * NTHREADS];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            ft[r][3 * half + s][xi] = R[3][s] + t[5 * s + 4];
-            R[3][s] = R[2][s] + t[5 * s + 3];
-            R[2][s] = R[1][s] + t[5 * s + 2];
-            R[1][s] = R[0][s] + t[5 * s + 1];
-            R[0][s] = t[5 * s];
+            ft[r][3 * half + s][xi] = R[3][s] + t[s][4];
+            if (r < 3) R[3][s] = R[2][s] + t[s][3];
+            if (r < 2) R[2][s] = R[1][s] + t[s][2];
+            if (r < 1) R[1][s] = R[0][s] + t[s][1];
         }
     }
     __syncthreads();

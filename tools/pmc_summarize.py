@@ -15,6 +15,7 @@ out = sys.argv[1]
 # kernels of one step: the strip kernel does the work; with seams (float32 mode) two small kernels finish the
 # rows / columns at item and strip boundaries -- their HBM bytes belong to the step's traffic
 KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seam_kernel", "srcnn_cseam_kernel"], "split16": ["srcnn_split16_kernel"]}
+traffic_rec = {}
 for mode, knames in KERNEL.items():
     kname = knames[0]
     sums, cnt = defaultdict(float), defaultdict(int)
@@ -67,11 +68,20 @@ for mode, knames in KERNEL.items():
     if stats_rows:
         with open(os.path.join(out, f"{mode}_4k_kernel_stats.csv"), "w", newline="") as fh:
             csv.writer(fh).writerows(stats_rows)
+    traffic_rec[("fused" if mode == "mfma" else mode) + "_3840x2160x1"] = d.get("hbm_bytes_step")
+    if "mfma_busy_frac_of_simd_cycles" in d:
+        traffic_rec[("fused" if mode == "mfma" else mode) + "_3840x2160x1_mfma_busy_frac"] = round(d["mfma_busy_frac_of_simd_cycles"], 4)
     summary = {"kernel": f"{kname} 3840x2160x1, {grid} workgroups", "rocprof_kernel_trace_avg_ns": avg_ns,
                "counters_mean_per_dispatch": mean, "derived": d}
     with open(os.path.join(out, f"{mode}_4k_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     print(mode, json.dumps(d), "avg_ns", avg_ns)
+
+traffic_rec["_note"] = ("per step (one 3840x2160 plane): HBM bytes of the strip kernel plus, in the float32 mode, the two seam kernels; "
+                        "FETCH_SIZE x2 for the strip kernels' byte loads (calibrated: profiles/r01/pmc_calibration.txt) + WRITE_SIZE, KB -> bytes; "
+                        "separate --pmc passes (tools/profile_round.sh); *_mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the strip kernel")
+with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+    json.dump(traffic_rec, fh, indent=1)
 
 # per-kernel averages of the other runs (rocprofv3 --stats): OUTDIR/other_kernels_stats.csv
 rows = [["run", "kernel", "calls", "avg_us"]]
