@@ -502,3 +502,14 @@ def test_random_weights_all_modes(gpu_ctx, weights_blob, seed):
     finally:
         gpu_ctx.set_mode(S.MODE_MFMA)
         gpu_ctx.set_weights_blob(weights_blob)
+
+
+def test_launch_geometry_reported_by_query_plan(gpu_ctx):
+    """A lone 3840x2160 plane: 30 strips of 128 output columns (column seams, no halo columns) cut into
+    2 x n_CU work items; a batch keeps the regular strip x segment grid over the same 30 strips."""
+    one = gpu_ctx.query_plan(3840, 2160, 1)
+    assert one["strips"] == 30 and one["workgroups"] % 2 == 0 and one["workgroups"] >= 256
+    batch = gpu_ctx.query_plan(3840, 2160, 64)
+    assert batch["strips"] == 30 and batch["workgroups"] == 30 * batch["segments"] * 64
+    narrow = gpu_ctx.query_plan(130, 700, 1)        # last strip would hold 2 columns: halo columns instead
+    assert narrow["strips"] == 2
