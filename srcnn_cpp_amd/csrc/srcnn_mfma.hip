@@ -37,11 +37,18 @@
 // finished per-tap-column values of a pixel cross lanes, through a small
 // double-buffered LDS tile, for the 5-term horizontal sum.
 //
-// HBM traffic of MODE_FUSED is ~1.1 B read + 1 B written per pixel; the kernel
-// is bound by the f32 MFMA pipe (130 MFMA x 64 cycles per 32 pixels per SIMD).
+// Nothing is computed twice.  The 5x5 layer couples a strip to its neighbours and a work item to
+// the items above and below it; instead of recomputing halo feature columns / rows, MODE_FUSED
+// hands the few boundary sums over: "row seams" between the work items of a strip and "column
+// seams" between strips (srcnn_kernels.h), finished by srcnn_seam_kernel / srcnn_cseam_kernel below
+// with the same additions in the same order (bit-identical to the halo-recompute form).
+//
+// HBM traffic of MODE_FUSED is ~1.1 B read + 1 B written per pixel plus the seam scratch (25 MB per
+// 3840x2160 plane, written and read once); the kernel is bound by the f32 MFMA pipe
+// (130 MFMA x 64 cycles per 32 pixels per SIMD).
 //
 // LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + F tiles 2x3x6x128 f32
-// (18 KiB) = 35 KiB; 216+ VGPRs -> two workgroups per CU, i.e. two waves per
+// (18 KiB) = 35 KiB; 243 VGPRs -> two workgroups per CU, i.e. two waves per
 // SIMD, so one wave's non-MFMA instructions are covered by the other's MFMAs.
 #include "srcnn_kernels.h"
 
