@@ -730,6 +730,21 @@ int srcnn_debug_read_sink(srcnn_ctx *c, void *dst, size_t bytes)
     return SRCNN_OK;
 }
 
+/* Undocumented test hook (not part of the ABI, needs no device): the work-item planner.  Fills `items`
+ * (ITEM_INTS ints each) and `seams` (2 ints each) up to the given capacities; returns the item count, or
+ * SRCNN_ERR_INVALID when a buffer is too small. */
+extern "C" int srcnn_debug_plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu,
+                                      int want_seams, int *items, int max_items, int *seams, int max_seams,
+                                      int *n_seams)
+{
+    const ItemPlan plan = plan_items(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams != 0);
+    if (plan.count() > max_items || plan.n_seams() > max_seams || !items || !seams || !n_seams) return SRCNN_ERR_INVALID;
+    std::memcpy(items, plan.items.data(), plan.items.size() * sizeof(int));
+    std::memcpy(seams, plan.seams.data(), plan.seams.size() * sizeof(int));
+    *n_seams = plan.n_seams();
+    return plan.count();
+}
+
 int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[6])
 {
     if (!c || !out || width <= 0 || height <= 0 || n_frames <= 0) return SRCNN_ERR_INVALID;

@@ -1,0 +1,75 @@
+"""CPU test of the work-item planner (plan_items() in srcnn_cpp_amd/csrc/srcnn_api.cpp) through an
+undocumented test hook of the library -- host logic only, no device needed.
+
+A plane launched alone is cut into per-block work items {strip, row range, seam above, seam below}.
+Whatever heights the planner picks for speed, the items must tile every strip exactly once, in
+order, and the seam ids must describe exactly the boundaries between vertically adjacent items:
+the kernels rely on that (an item leaves the two output rows next to a seam to the seam kernel).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import srcnn_cpp_amd as S
+
+ITEM_INTS = 5
+
+
+def plan(n_cu, n_strips, r0, r1, skew=10, per_cu=2, seams=True):
+    lib = S.load_library()
+    fn = lib.srcnn_debug_plan_items
+    fn.restype = C.c_int
+    items = (C.c_int * (ITEM_INTS * 4096))()
+    seam = (C.c_int * (2 * 4096))()
+    n_seams = C.c_int(0)
+    n = fn(n_cu, n_strips, r0, r1, skew, per_cu, int(seams), items, 4096, seam, 4096, C.byref(n_seams))
+    assert n >= 0
+    it = np.array(items[:ITEM_INTS * n], dtype=np.int64).reshape(n, ITEM_INTS)
+    se = np.array(seam[:2 * n_seams.value], dtype=np.int64).reshape(n_seams.value, 2)
+    return it, se
+
+
+GEOMETRIES = [(256, 30, 0, 2160), (256, 31, 0, 2160), (256, 15, 0, 1080), (256, 60, 0, 4320), (256, 62, 540, 1080),
+              (256, 10, 0, 720), (256, 1, 0, 6400), (256, 2, 0, 6400), (256, 45, 100, 3340), (32, 8, 0, 1080),
+              (256, 4, 0, 540), (304, 31, 0, 2160), (256, 256, 0, 2160), (256, 200, 0, 600)]
+
+
+@pytest.mark.parametrize("n_cu,n_strips,r0,r1", GEOMETRIES)
+@pytest.mark.parametrize("per_cu", [1, 2])
+@pytest.mark.parametrize("seams", [False, True])
+def test_items_tile_every_strip_exactly(n_cu, n_strips, r0, r1, per_cu, seams):
+    it, se = plan(n_cu, n_strips, r0, r1, per_cu=per_cu, seams=seams)
+    if len(it) == 0:
+        return                                   # geometry does not qualify: the regular grid is used
+    assert len(it) == per_cu * n_cu              # every workgroup slot gets exactly one item
+    used_seams = set()
+    for s in range(n_strips):
+        mine = it[it[:, 0] == s]
+        mine = mine[np.argsort(mine[:, 1])]
+        assert len(mine) >= 2
+        assert mine[0, 1] == r0 and mine[-1, 2] == r1
+        assert (mine[1:, 1] == mine[:-1, 2]).all(), "gap or overlap between the items of a strip"
+        assert (mine[:, 2] > mine[:, 1]).all()
+        assert mine[0, 3] == -1 and mine[-1, 4] == -1, "seam at the edge of the launch"
+        for a, b in zip(mine[:-1], mine[1:]):
+            assert a[4] == b[3], "the two items at a boundary name different seams"
+            if a[4] >= 0:
+                assert tuple(se[a[4]]) == (s, a[2])
+                assert a[4] not in used_seams
+                used_seams.add(int(a[4]))
+    if len(se):
+        assert used_seams == set(range(len(se)))
+        assert ((it[:, 2] - it[:, 1]) >= 8).all(), "an item next to a seam must hold the 4 rows it hands over"
+    else:
+        assert (it[:, 3:] == -1).all()
+
+
+def test_fast_and_slow_items_pair_up_per_cu():
+    """Two workgroups per CU: block i and block n_cu + i share a CU (measured), so their heights must
+    complement each other -- every CU carries (nearly) the same number of rows."""
+    it, _ = plan(256, 30, 0, 2160)
+    h = it[:, 2] - it[:, 1]
+    per_cu = h[:256] + h[256:]
+    assert per_cu.max() - per_cu.min() <= 0.05 * per_cu.mean()
+    assert h[:256].mean() > 1.1 * h[256:].mean()          # first-dispatched blocks are the taller ones
