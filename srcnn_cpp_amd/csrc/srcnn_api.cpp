@@ -321,13 +321,19 @@ ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew
                     bool want_seams = false)
 {
     const ItemPlan none;
-    const int rows = row_end - row_begin, slots = wgs_per_cu * n_cu;
+    const int rows = row_end - row_begin;
+    int slots = wgs_per_cu * n_cu;
     // shortest useful item: with halo rows to recompute (4 per item) short items do not pay; with seams an item
     // only has to be tall enough for the hand-over (2 * SEAM_ROWS, 10 for some slack in the skewed heights)
     const int min_rows = want_seams ? 10 : 24;
-    if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu || slots / n_strips < 2 ||
-        rows / (slots / n_strips + 1) < min_rows)
-        return none;
+    if (skew_pct <= 0 || n_strips <= 0 || n_strips > n_cu) return none;
+    // one item per CU: a small plane may leave CUs idle rather than cut its strips into items shorter than that
+    bool underfilled = false;
+    if (wgs_per_cu == 1 && want_seams && rows / min_rows < slots / n_strips + 1) {
+        slots = n_strips * (rows / min_rows);       // every strip in rows / min_rows items of >= min_rows rows
+        underfilled = true;
+    }
+    if (slots / n_strips < 2 || (!underfilled && rows / (slots / n_strips + 1) < min_rows)) return none;
     if (wgs_per_cu == 1) skew_pct = 0;
     const int kbase = slots / n_strips, kextra = slots % n_strips;      // strips [0,kextra) get kbase+1 items
     std::vector<int> k(n_strips), a(n_strips);
@@ -341,7 +347,7 @@ ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew
         if (k[s] % 2 == 1 && a[s] < k[s] - 1) { ++a[s]; ++fast_total; }
     for (int s = 0; fast_total < n_cu && s < n_strips; ++s)
         if (a[s] < k[s] - 1) { ++a[s]; ++fast_total; }
-    if (fast_total != n_cu) return none;
+    if (wgs_per_cu == 2 && fast_total != n_cu) return none;
     const double d = skew_pct / 100.0;
     std::vector<std::vector<int>> bounds(n_strips);
     for (int s = 0; s < n_strips; ++s) {
@@ -471,6 +477,11 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
             const int ns_cs = (p.width + FW - 1) / FW;
             if (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1) {
                 if ((rc = build_items(c, ns_cs, p.row_begin, p.row_end, wgs_per_cu, true, &table))) return rc;
+                // a plane too small for two items per CU of useful height: one (taller) item per CU still beats
+                // the regular grid with its halo rows
+                if (table->count == 0 && wgs_per_cu == 2 &&
+                    (rc = build_items(c, ns_cs, p.row_begin, p.row_end, 1, true, &table)))
+                    return rc;
                 if (table->count > 0) p.strips_total = ns_cs;
                 else table = nullptr;
             }
@@ -756,9 +767,14 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     const int ns_cs = (width + FW - 1) / FW;
     bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (n_frames > 1 || (seam_knob & 1)) &&
                      (width - (ns_cs - 1) * FW >= 4 || ns_cs == 1);
+    int items_per_cu = wgs_per_cu;
     if (col_seams && n_frames == 1 &&
-        plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), wgs_per_cu, true).items.empty())
-        col_seams = false;
+        plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), wgs_per_cu, true).items.empty()) {
+        if (wgs_per_cu == 2 && !plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), 1, true).items.empty())
+            items_per_cu = 1;
+        else
+            col_seams = false;
+    }
     const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu, col_seams ? 0 : -1);
     out[0] = pl.n_strips * pl.n_segs * n_frames;
     out[1] = pl.seg_rows;
@@ -766,7 +782,7 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[3] = pl.n_segs;
     if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
         const std::vector<int> items =
-            plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), wgs_per_cu,
+            plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), items_per_cu,
                        c->mode == SRCNN_MODE_MFMA && (seam_knob & 1)).items;
         if (!items.empty()) {
             out[0] = (int)items.size() / ITEM_INTS;
