@@ -3,7 +3,7 @@
 (oracle) on a full 3840x2160 synthetic frame -- the numbers DESIGN.md section 5 quotes."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 import oracle
 import srcnn_cpp_amd as S

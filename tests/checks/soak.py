@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised soak of the HIP path against the oracle (run on the GPU box; not part of pytest).
 
-usage: python tools/soak.py [seconds] [seed]
+usage: python tests/checks/soak.py [seconds] [seed]
 Random plane sizes (biased to strip / unit / item-planner boundaries), padded strides, three
 content types; every result is checked: float32 MFMA mode bitwise against the FMA-order model and
 within tolerance of the reference arithmetic, split-f16 mode within tolerance, exact mode bitwise.
 """
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import oracle, srcnn_cpp_amd as S
 from srcnn_cpp_amd.synth import synth_luma

@@ -2,7 +2,7 @@
 """Accuracy of SRCNN_MODE_SPLIT16 and SRCNN_MODE_MFMA against the oracle on the 4K bench frame."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 import oracle, srcnn_cpp_amd as S
 from srcnn_cpp_amd.synth import synth_luma

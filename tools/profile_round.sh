@@ -33,8 +33,8 @@ tools/measure_all.sh $OUT/measurements.jsonl > /dev/null 2>&1
 python tools/diag_stamps.py > $OUT/diag_stamps_mfma.txt 2>&1
 DIAG_BLOCKS=512 python tools/diag_stamps.py > /dev/null 2>&1
 python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
-python tools/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
-python tools/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
+python tests/checks/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
+python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
 [ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
 [ -x build/mfma_probe ] && ./build/mfma_probe > $OUT/mfma_probe.txt 2>&1
 # keep the merge small: the raw per-dispatch csv files are summarised on the box
