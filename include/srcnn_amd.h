@@ -22,7 +22,13 @@
  *     functions return void and are unchecked); never throws;
  *   - a context is bound to one GPU and one HIP stream and is NOT internally
  *     locked: use one context per host thread (the reference calls the path
- *     from a single worker thread, src/srcnn.cpp:720).
+ *     from a single worker thread, src/srcnn.cpp:720).  Every call makes the
+ *     context's GPU current for its own duration and restores the caller's.
+ *   - the *_dev entry points are ordered on the context's CURRENT stream only:
+ *     after srcnn_set_stream, work still queued on the previous stream must be
+ *     synchronised by the caller before buffers it uses are touched again
+ *     (context-owned scratch is per stream; growing it waits for the device).
+ *   - no entry point works in place: src and dst must not overlap.
  *   - there is NO CPU fallback: without a usable gfx950 device srcnn_create
  *     fails with SRCNN_ERR_NODEVICE.
  */
@@ -133,6 +139,45 @@ int srcnn_forward_y(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
  * dst[i] is complete. */
 int srcnn_forward_y_frames(srcnn_ctx *ctx, const uint8_t *const *src, size_t src_stride,
                            uint8_t *const *dst, size_t dst_stride, int width, int height, int n_frames);
+
+/* ---- several GPUs driven from ONE host process ------------------ *
+ * One context per GPU (several contexts on one GPU also work), one host thread   *
+ * per context inside the call, no collective library: frames are independent,    *
+ * and a row-striped plane needs only its neighbours' 6 boundary rows, copied     *
+ * device to device (hipMemcpyPeerAsync over xGMI).  These serve the reference's  *
+ * two call sites src/srcnn.cpp:609,627 when the caller owns more than one GPU;   *
+ * the reference's own parallelism is the row-parallel loop at :283-284, which    *
+ * row striping generalises.  Every context needs srcnn_set_weights.              */
+
+/* Balanced contiguous split used by the calls below: part `index` of `n_parts`
+ * owns [*row_begin, *row_end) of `height` rows (or frames); the first
+ * height % n_parts parts get one extra. */
+int srcnn_stripe_rows(int height, int n_parts, int index, int *row_begin, int *row_end);
+
+/* A stream of n_frames host frames over n_ctx contexts: context k runs
+ * srcnn_forward_y_frames on its contiguous range of frames.  Returns when every
+ * dst[i] is complete. */
+int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx,
+                                 const uint8_t *const *src, size_t src_stride,
+                                 uint8_t *const *dst, size_t dst_stride,
+                                 int width, int height, int n_frames);
+
+/* ONE width x height host plane row-striped over n_ctx contexts: context k
+ * uploads only its own rows srcnn_stripe_rows(height, n_ctx, k), the 6 halo rows
+ * per boundary travel device to device, the interior rows are launched while
+ * those copies are in flight and the two 6-row edge bands after them.  The
+ * result is bit-identical to srcnn_forward_y.  Needs height / n_ctx >= 6. */
+int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx,
+                            const uint8_t *src, size_t src_stride,
+                            uint8_t *dst, size_t dst_stride, int width, int height);
+
+/* Same on device memory: d_stripes[k] / d_out[k] are DEVICE pointers on
+ * ctxs[k]'s GPU to that context's rows of the input / output plane.  The inputs
+ * must be complete when the call is made; the work is asynchronous on each
+ * context's stream (srcnn_synchronize every context to wait). */
+int srcnn_forward_y_striped_dev(srcnn_ctx *const *ctxs, int n_ctx,
+                                const uint8_t *const *d_stripes, size_t stripe_stride,
+                                uint8_t *const *d_out, size_t out_stride, int width, int height);
 
 /* ---- device-resident entry points (pointers are DEVICE memory) ------------- *
  * Asynchronous on the context's stream; the caller synchronises.               */

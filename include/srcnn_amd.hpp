@@ -158,6 +158,76 @@ inline void ForwardY(MatU8 &src, MatU8 &dst, const float kernel99[64][9][9], con
                             src.rows, nullptr, 0));
 }
 
+// ---- more than one GPU from one host (srcnn_amd.h "several GPUs") -----------------------
+// One context per entry of `devices` (a device may appear more than once); the model is uploaded to each.
+class SessionSet {
+public:
+    explicit SessionSet(const std::vector<int> &devices)
+    {
+        for (int d : devices) {
+            srcnn_ctx *c = nullptr;
+            const int rc = srcnn_create(&c, d);
+            if (rc != SRCNN_OK) {
+                for (srcnn_ctx *p : ctxs_) srcnn_destroy(p);
+                throw Error(rc, "srcnn_create failed (a gfx950 GPU is required)");
+            }
+            ctxs_.push_back(c);
+        }
+        if (ctxs_.empty()) throw Error(SRCNN_ERR_INVALID, "SessionSet: no devices");
+    }
+    ~SessionSet() { for (srcnn_ctx *c : ctxs_) srcnn_destroy(c); }
+    SessionSet(const SessionSet &) = delete;
+    SessionSet &operator=(const SessionSet &) = delete;
+    int size() const { return (int)ctxs_.size(); }
+    srcnn_ctx *const *data() const { return ctxs_.data(); }
+    void set_weights(const float kernel99[64][9][9], const float bias99[64], const float kernel11[32][64],
+                     const float bias11[32], const float kernel55[32][5][5], float bias55)
+    {
+        for (srcnn_ctx *c : ctxs_) {
+            const int rc = srcnn_set_weights(c, &kernel99[0][0][0], bias99, &kernel11[0][0], bias11, &kernel55[0][0][0], bias55);
+            if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(c));
+        }
+    }
+    void check(int rc) const
+    {
+        if (rc == SRCNN_OK) return;
+        std::string msg;
+        for (srcnn_ctx *c : ctxs_) msg += std::string(msg.empty() ? "" : " | ") + srcnn_last_error(c);
+        throw Error(rc, msg);
+    }
+
+private:
+    std::vector<srcnn_ctx *> ctxs_;
+};
+
+// ONE plane row-striped over the set's GPUs (6 halo rows per boundary device to device): same bytes as ForwardY.
+template <class MatU8>
+inline void ForwardYStriped(SessionSet &set, MatU8 &src, MatU8 &dst)
+{
+    set.check(srcnn_forward_y_striped(set.data(), set.size(), detail::ptr<const std::uint8_t>(src),
+                                      detail::stride<std::uint8_t>(src), detail::ptr<std::uint8_t>(dst),
+                                      detail::stride<std::uint8_t>(dst), src.cols, src.rows));
+}
+
+// A stream of equally sized planes, contiguous frame ranges per GPU, no collective.
+template <class MatU8>
+inline void ForwardYFrames(SessionSet &set, std::vector<MatU8> &src, std::vector<MatU8> &dst)
+{
+    if (src.empty() || src.size() != dst.size()) throw Error(SRCNN_ERR_INVALID, "ForwardYFrames: need as many outputs as inputs");
+    std::vector<const std::uint8_t *> in(src.size());
+    std::vector<std::uint8_t *> out(src.size());
+    for (std::size_t i = 0; i < src.size(); ++i) {
+        if (src[i].rows != src[0].rows || src[i].cols != src[0].cols || dst[i].rows != src[0].rows || dst[i].cols != src[0].cols ||
+            detail::stride<std::uint8_t>(src[i]) != detail::stride<std::uint8_t>(src[0]) ||
+            detail::stride<std::uint8_t>(dst[i]) != detail::stride<std::uint8_t>(dst[0]))
+            throw Error(SRCNN_ERR_INVALID, "ForwardYFrames: frames must share size and row stride");
+        in[i] = detail::ptr<const std::uint8_t>(src[i]);
+        out[i] = detail::ptr<std::uint8_t>(dst[i]);
+    }
+    set.check(srcnn_forward_y_frames_multi(set.data(), set.size(), in.data(), detail::stride<std::uint8_t>(src[0]), out.data(),
+                                           detail::stride<std::uint8_t>(dst[0]), src[0].cols, src[0].rows, (int)src.size()));
+}
+
 // The timed region of the reference's pipeline driver (src/srcnn.cpp:505-659) with the
 // buffer-level shape of the sibling library's ProcessSRCNN (src/test.cpp:347-353):
 // packed B,G,R bytes in, packed B,G,R bytes out at (int)(w*scale) x (int)(h*scale).

@@ -76,6 +76,23 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def build_o0() -> Path:
+    """The restatement at -O0, the reference's effective flags (reference Makefile:21-23,43); timed only."""
+    out = _HERE / "libsrcnn_oracle_O0.so"
+    if not out.exists() or out.stat().st_mtime < (_HERE / "srcnn_oracle.c").stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "o0"], check=True, stdout=subprocess.DEVNULL)
+    return out
+
+
+def bind_forward(cdll):
+    """forward(src, blob) -> u8 plane on an alternative build of srcnn_oracle.c (see build_o0)."""
+    cdll.srcnn_oracle_forward_y.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _f32p, _f32p]
+
+    def forward(src, blob):
+        return _forward(cdll.srcnn_oracle_forward_y, src, blob)[0]
+    return forward
+
+
 def set_threads(n: int) -> None:
     """OpenMP thread count for subsequent oracle calls (libgomp honours the env
     only at first use, so go through omp_set_num_threads)."""

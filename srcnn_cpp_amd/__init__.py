@@ -29,6 +29,7 @@ __all__ = [
     "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
     "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "FLOP_PER_PIXEL",
+    "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -107,6 +108,10 @@ def load_library() -> C.CDLL:
         "srcnn_resize_cubic": ([vp, _u8p, sz, i, i, _u8p, sz, i, i], i),
         "srcnn_process_bgr": ([vp, _u8p, sz, i, i, C.c_float, _u8p, sz], i),
         "srcnn_process_bgr_dev": ([vp, vp, sz, i, i, C.c_float, vp, sz], i),
+        "srcnn_stripe_rows": ([i, i, i, C.POINTER(i), C.POINTER(i)], i),
+        "srcnn_forward_y_frames_multi": ([C.POINTER(vp), i, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
+        "srcnn_forward_y_striped": ([C.POINTER(vp), i, _u8p, sz, _u8p, sz, i, i], i),
+        "srcnn_forward_y_striped_dev": ([C.POINTER(vp), i, C.POINTER(vp), sz, C.POINTER(vp), sz, i, i], i),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
@@ -124,6 +129,7 @@ ABI_SYMBOLS = (
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
+    "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
 
 
@@ -151,6 +157,14 @@ def _plane(a, dtype, name, writable=False):
     if writable and not a.flags.writeable:
         raise ValueError(f"{name}: output plane is read-only")
     return a, a.strides[0] // a.itemsize
+
+
+def _same_shape(name, got, want):
+    """Every plane of a call has the dims the C side takes from ONE of them (the reference reads them from
+    dst or src, src/srcnn.cpp:94-95, :262-263, and never checks the others): a smaller buffer would be
+    overrun by the device-to-host copies, so reject it here."""
+    if tuple(got) != tuple(want):
+        raise ValueError(f"{name}: shape {tuple(got)} does not match the call's plane shape {tuple(want)}")
 
 
 def _fp(a):
@@ -240,30 +254,34 @@ class Context:
         dst, ds = _plane(dst, np.float32, "dst", True)
         k = _wt(kernel, 81, "kernel")
         h, w = dst.shape                       # dims come from dst: src/srcnn.cpp:94-95
+        _same_shape("src", src.shape, dst.shape)
         self._check(self._lib.srcnn_conv99(self._h, src.ctypes.data_as(_u8p), ss, _fp(dst), ds, w, h,
                                            _fp(k), float(bias)))
 
     def conv11(self, src, dst, kernel, bias):
-        arr, ss, _ = _ptr_array(src, 64, "src")
+        arr, ss, shape = _ptr_array(src, 64, "src")
         dst, ds = _plane(dst, np.float32, "dst", True)
         k = _wt(kernel, 64, "kernel")
         h, w = dst.shape
+        _same_shape("src planes", shape, dst.shape)
         self._check(self._lib.srcnn_conv11(self._h, arr, ss, _fp(dst), ds, w, h, _fp(k), float(bias)))
 
     def conv55(self, src, dst, kernel, bias):
-        arr, ss, _ = _ptr_array(src, 32, "src")
+        arr, ss, shape = _ptr_array(src, 32, "src")
         dst, ds = _plane(dst, np.uint8, "dst", True)
         k = _wt(kernel, 800, "kernel")
         h, w = dst.shape
+        _same_shape("src planes", shape, dst.shape)
         self._check(self._lib.srcnn_conv55(self._h, arr, ss, dst.ctypes.data_as(_u8p), ds, w, h,
                                            _fp(k), float(bias)))
 
     def conv99x11(self, src, dst, k99, b99, k11, b11):
         src, ss = _plane(src, np.uint8, "src")
-        arr, ds, _ = _ptr_array(dst, 32, "dst", True)
+        arr, ds, shape = _ptr_array(dst, 32, "dst", True)
         k99, b99 = _wt(k99, 5184, "kernel99"), _wt(b99, 64, "bias99")
         k11, b11 = _wt(k11, 2048, "kernel11"), _wt(b11, 32, "bias11")
         h, w = src.shape                       # dims come from src: src/srcnn.cpp:262-263
+        _same_shape("dst planes", shape, src.shape)
         self._check(self._lib.srcnn_conv99x11(self._h, src.ctypes.data_as(_u8p), ss, arr, ds, w, h,
                                               _fp(k99), _fp(b99), _fp(k11), _fp(b11)))
 
@@ -274,9 +292,11 @@ class Context:
         if dst is None:
             dst = np.empty((h, w), np.uint8)
         dst, ds = _plane(dst, np.uint8, "dst", True)
+        _same_shape("dst", dst.shape, src.shape)
         pp, ps = None, 0
         if preclamp is not None:
             preclamp, ps = _plane(preclamp, np.float32, "preclamp", True)
+            _same_shape("preclamp", preclamp.shape, src.shape)
             pp = _fp(preclamp)
         self._check(self._lib.srcnn_forward_y(self._h, src.ctypes.data_as(_u8p), ss,
                                               dst.ctypes.data_as(_u8p), ds, w, h, pp, ps))
@@ -285,9 +305,16 @@ class Context:
     def forward_y_frames(self, frames, out=None):
         """A stream of equally sized host frames ([n,h,w] uint8), PCIe transfers overlapped with compute."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim != 3 or 0 in frames.shape:
+            raise ValueError("frames: expected a non-empty [n, h, w] uint8 array")
         n, h, w = frames.shape
         if out is None:
             out = np.empty_like(frames)
+        if not isinstance(out, np.ndarray) or out.dtype != np.uint8:
+            raise TypeError("out: expected a uint8 numpy array")
+        _same_shape("out", out.shape, frames.shape)
+        if not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("out: must be C-contiguous and writeable")
         srcs = (_u8p * n)(*[frames[k].ctypes.data_as(_u8p) for k in range(n)])
         dsts = (_u8p * n)(*[out[k].ctypes.data_as(_u8p) for k in range(n)])
         self._check(self._lib.srcnn_forward_y_frames(self._h, srcs, w, dsts, w, w, h, n))
@@ -396,6 +423,71 @@ def process_bgr_dev(self, d_bgr, stride, width, height, scale, d_out, out_stride
     self._check(self._lib.srcnn_process_bgr_dev(self._h, d_bgr, stride, width, height, float(scale),
                                                 d_out, out_stride))
 
+
+def stripe_rows(height: int, n_parts: int, index: int):
+    """[begin, end) of part `index` of `n_parts` (srcnn_stripe_rows; equals sharding.split_range)."""
+    a, b = C.c_int(), C.c_int()
+    rc = load_library().srcnn_stripe_rows(height, n_parts, index, C.byref(a), C.byref(b))
+    if rc != 0:
+        raise SrcnnError(rc, "bad split")
+    return a.value, b.value
+
+
+def _ctx_array(ctxs):
+    if not ctxs:
+        raise ValueError("need at least one context")
+    return (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+
+
+def forward_y_frames_multi(ctxs: Sequence[Context], frames, out=None):
+    """A stream of host frames over several contexts / GPUs (srcnn_forward_y_frames_multi)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    if frames.ndim != 3 or 0 in frames.shape:
+        raise ValueError("frames: expected a non-empty [n, h, w] uint8 array")
+    n, h, w = frames.shape
+    if out is None:
+        out = np.empty_like(frames)
+    if not isinstance(out, np.ndarray) or out.dtype != np.uint8:
+        raise TypeError("out: expected a uint8 numpy array")
+    _same_shape("out", out.shape, frames.shape)
+    if not out.flags.c_contiguous or not out.flags.writeable:
+        raise ValueError("out: must be C-contiguous and writeable")
+    srcs = (_u8p * n)(*[frames[k].ctypes.data_as(_u8p) for k in range(n)])
+    dsts = (_u8p * n)(*[out[k].ctypes.data_as(_u8p) for k in range(n)])
+    ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_frames_multi(_ctx_array(ctxs), len(ctxs), srcs, w, dsts, w,
+                                                                          w, h, n))
+    return out
+
+
+def forward_y_striped(ctxs: Sequence[Context], src, dst=None):
+    """ONE host plane row-striped over several contexts / GPUs (srcnn_forward_y_striped)."""
+    src, ss = _plane(src, np.uint8, "src")
+    h, w = src.shape
+    if dst is None:
+        dst = np.empty((h, w), np.uint8)
+    dst, ds = _plane(dst, np.uint8, "dst", True)
+    _same_shape("dst", dst.shape, src.shape)
+    ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_striped(_ctx_array(ctxs), len(ctxs), src.ctypes.data_as(_u8p),
+                                                                     ss, dst.ctypes.data_as(_u8p), ds, w, h))
+    return dst
+
+
+def forward_y_striped_dev(ctxs: Sequence[Context], d_stripes, stripe_stride, d_out, out_stride, width, height):
+    """Device-resident striped step: d_stripes[k] / d_out[k] are integer device addresses on ctxs[k]'s GPU."""
+    n = len(ctxs)
+    ins = (C.c_void_p * n)(*[int(p) for p in d_stripes])
+    outs = (C.c_void_p * n)(*[int(p) for p in d_out])
+    ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_striped_dev(_ctx_array(ctxs), n, ins, stripe_stride, outs,
+                                                                         out_stride, width, height))
+
+
+def _check_multi(self, ctxs, rc):
+    if rc != 0:
+        msgs = [self._lib.srcnn_last_error(c._h).decode() for c in ctxs]
+        raise SrcnnError(rc, " | ".join(m for m in msgs if m != "no error") or "multi-context call failed")
+
+
+Context._check_multi = _check_multi
 
 _default: Optional[Context] = None
 

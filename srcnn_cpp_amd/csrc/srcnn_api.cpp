@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace srcnn;
@@ -70,6 +71,18 @@ struct srcnn_ctx {
     static constexpr int kItemTables = 8;
     ItemTable item_tables[kItemTables];
     unsigned long item_clock = 0;
+    // host copy of the uploaded tables in convdata.h order: the per-call weight arguments of the reference surface
+    // (srcnn_conv99x11 / srcnn_conv55) are compared against it, and equal tables are not packed or uploaded again
+    std::vector<float> host_raw = std::vector<float>(8129, 0.f);
+    // pinned staging of the reference surface's 32 planes (two slots, alternating) and of single planes
+    void *pin_plane[2] = {nullptr, nullptr};
+    size_t pin_plane_cap = 0;
+    // row-striped multi-device step (srcnn_forward_y_striped*): second stream for the halo copies, band inputs
+    // [6 halo rows | 12 own rows] / [12 own rows | 6 halo rows], events ordering the two streams
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t halo_ready = nullptr, bands_done = nullptr;
+    bool bands_pending = false;
+    DevBuf band_top, band_bot, stripe_ext;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
@@ -97,18 +110,39 @@ int fail(srcnn_ctx *c, int code, const char *fmt, ...)
                         "%s failed: %s", #expr, hipGetErrorString(e_));                         \
     } while (0)
 
-int bind(srcnn_ctx *c)
-{
-    if (!c) return SRCNN_ERR_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
-    return SRCNN_OK;
-}
+// Every entry point makes the context's device current for its own duration and puts the caller's device
+// back on return (a framework sharing the thread keeps ITS current device).
+struct DeviceScope {
+    int prev = -1, rc = SRCNN_OK;
+    explicit DeviceScope(srcnn_ctx *c)
+    {
+        if (!c) { rc = SRCNN_ERR_INVALID; return; }
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) {
+            const hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) {
+                rc = fail(c, SRCNN_ERR_HIP, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e));
+                prev = -1;
+            }
+        } else {
+            prev = -1;      // nothing to restore
+        }
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define BIND(c)                 \
+    DeviceScope dev_scope_(c);  \
+    if (dev_scope_.rc) return dev_scope_.rc
 
+// Context-owned buffers may be in use by work queued on ANY stream the context was given
+// (srcnn_set_stream), so growing one waits for the whole device, not just the current stream.
 int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return SRCNN_OK;
     if (b.p) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -254,14 +288,26 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     if ((rc = reserve(c, c->wfrag16, frag16.size()))) return rc;
     if ((rc = reserve(c, c->sink, 1 << 20))) return rc;   // scratch words (+ diagnostics in debug builds)
     if ((rc = reserve(c, c->wraw, raw.size() * 4))) return rc;
-    // synchronous copies: the host vectors die at return
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // synchronous copies: the host vectors die at return; launches on any stream may still read the old tables
+    HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(c->wfrag.p, frag.data(), frag.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->wraw.p, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->wfrag16.p, frag16.data(), frag16.size(), hipMemcpyHostToDevice));
     c->b3 = b55;
     c->split16_ok = split16_range_ok(w1, b1, w2, b2, w3);
+    std::memcpy(c->host_raw.data(), raw.data(), 8129 * sizeof(float));
     return SRCNN_OK;
+}
+
+// Do two element ranges of the same device address space overlap?  (first byte, one past the last byte)
+bool ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes)
+{
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    return a0 < b0 + b_bytes && b0 < a0 + a_bytes;
+}
+size_t span_elems(size_t stride, size_t frame_pitch, int width, int height, int n_frames)
+{
+    return (size_t)(n_frames - 1) * frame_pitch + (size_t)(height - 1) * stride + (size_t)width;
 }
 
 struct Plan {
@@ -636,6 +682,96 @@ int process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int w, in
     return SRCNN_OK;
 }
 
+// The reference surface moves 32 separately allocated float planes per call (std::vector<cv::Mat>,
+// src/srcnn.cpp:602-607): 128 B/pixel over PCIe, 1.06 GB at 3840x2160.  Pageable-memory copies are staged by the
+// runtime one after the other; here each plane crosses PCIe into / out of one of two PINNED slots while a few host
+// threads copy the previous plane between its slot and the caller's memory.
+int reserve_pin_planes(srcnn_ctx *c, size_t bytes)
+{
+    if (c->pin_plane_cap >= bytes) return SRCNN_OK;
+    for (int k = 0; k < 2; ++k) {
+        if (c->pin_plane[k]) (void)hipHostFree(c->pin_plane[k]);
+        c->pin_plane[k] = nullptr;
+    }
+    c->pin_plane_cap = 0;
+    for (int k = 0; k < 2; ++k) HIP_TRY(c, hipHostMalloc(&c->pin_plane[k], bytes, hipHostMallocDefault));
+    c->pin_plane_cap = bytes;
+    return SRCNN_OK;
+}
+
+// rows of `width` elements between a packed buffer and a strided one, split over a few threads
+template <typename T>
+void copy_rows_mt(T *dst, size_t dst_stride, const T *src, size_t src_stride, int width, int height)
+{
+    static const int n_thr = [] {
+        const char *e = std::getenv("SRCNN_HOST_COPY_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(1, e ? std::atoi(e) : std::min(8, hw > 0 ? hw / 2 : 4));
+    }();
+    auto part = [=](int y0, int y1) {
+        if (dst_stride == (size_t)width && src_stride == (size_t)width)
+            std::memcpy(dst + (size_t)y0 * width, src + (size_t)y0 * width, (size_t)(y1 - y0) * width * sizeof(T));
+        else
+            for (int y = y0; y < y1; ++y) std::memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * src_stride, (size_t)width * sizeof(T));
+    };
+    const int nt = (int)std::min<size_t>((size_t)n_thr, std::max<size_t>(1, (size_t)width * height * sizeof(T) >> 20));   // >= 1 MB per thread
+    if (nt <= 1) { part(0, height); return; }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(part, (int)((long)height * t / nt), (int)((long)height * (t + 1) / nt));
+    part(0, height / nt);
+    for (auto &th : pool) th.join();
+}
+
+// device planes (packed, plane k at d_planes + k * pitch) -> the caller's n_planes host planes
+int planes_to_host(srcnn_ctx *c, const float *d_planes, size_t pitch, float *const *dst, size_t dst_stride, int width,
+                   int height, int n_planes)
+{
+    const size_t bytes = (size_t)width * height * sizeof(float);
+    int rc;
+    if ((rc = reserve_pin_planes(c, bytes))) return rc;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    for (int k = 0; k <= n_planes && e == hipSuccess; ++k) {
+        if (k < n_planes) {
+            e = hipMemcpyAsync(c->pin_plane[k & 1], d_planes + pitch * k, bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(ev[k & 1], c->stream);
+        }
+        if (k > 0 && e == hipSuccess) {        // plane k-1 has landed in its slot: hand it over while plane k is in flight
+            e = hipEventSynchronize(ev[(k - 1) & 1]);
+            if (e == hipSuccess)
+                copy_rows_mt(dst[k - 1], dst_stride, static_cast<const float *>(c->pin_plane[(k - 1) & 1]), (size_t)width, width, height);
+        }
+    }
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
+    if (e != hipSuccess) return fail(c, SRCNN_ERR_HIP, "planes_to_host: %s", hipGetErrorString(e));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+// the caller's n_planes host planes -> device planes (packed); asynchronous tail on the context's stream
+int planes_from_host(srcnn_ctx *c, const float *const *src, size_t src_stride, float *d_planes, size_t pitch, int width,
+                     int height, int n_planes)
+{
+    const size_t bytes = (size_t)width * height * sizeof(float);
+    int rc;
+    if ((rc = reserve_pin_planes(c, bytes))) return rc;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < n_planes && e == hipSuccess; ++k) {
+        if (k >= 2) e = hipEventSynchronize(ev[k & 1]);         // the slot's previous upload has left it
+        if (e != hipSuccess) break;
+        copy_rows_mt(static_cast<float *>(c->pin_plane[k & 1]), (size_t)width, src[k], src_stride, width, height);
+        e = hipMemcpyAsync(d_planes + pitch * k, c->pin_plane[k & 1], bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[k & 1], c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the pinned slots are free again
+    for (int k = 0; k < 2; ++k) (void)hipEventDestroy(ev[k]);
+    if (e != hipSuccess) return fail(c, SRCNN_ERR_HIP, "planes_from_host: %s", hipGetErrorString(e));
+    return SRCNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -668,11 +804,18 @@ int srcnn_create(srcnn_ctx **out, int device)
 void srcnn_destroy(srcnn_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceScope dev_scope_(c);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();          // work on any stream the context was given may still use its buffers
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
-                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16})
+                      &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16,
+                      &c->band_top, &c->band_bot, &c->stripe_ext})
         release(*b);
+    for (int k = 0; k < 2; ++k)
+        if (c->pin_plane[k]) (void)hipHostFree(c->pin_plane[k]);
+    if (c->halo_ready) (void)hipEventDestroy(c->halo_ready);
+    if (c->bands_done) (void)hipEventDestroy(c->bands_done);
+    if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
     for (auto &sc : c->seam_scratch) {
         release(sc.buf);
         release(sc.cbuf);
@@ -713,8 +856,9 @@ int srcnn_set_stream(srcnn_ctx *c, void *hip_stream)
 
 int srcnn_synchronize(srcnn_ctx *c)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SRCNN_OK;
 }
@@ -722,9 +866,15 @@ int srcnn_synchronize(srcnn_ctx *c)
 int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11,
                       const float *k55, float b55)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!k99 || !b99 || !k11 || !b11 || !k55) return fail(c, SRCNN_ERR_INVALID, "null weight table");
+    // a caller that passes its const tables on every call (the reference does, src/srcnn.cpp:609,627) packs and uploads once
+    const float *hr = c->host_raw.data();
+    if (c->has_weights && hr[7328] == b55 && !std::memcmp(hr, b99, 64 * 4) && !std::memcmp(hr + 64, k99, 5184 * 4) &&
+        !std::memcmp(hr + 5248, b11, 32 * 4) && !std::memcmp(hr + 5280, k11, 2048 * 4) && !std::memcmp(hr + 7329, k55, 800 * 4))
+        return SRCNN_OK;
     if ((rc = upload_weights(c, k99, b99, k11, b11, k55, b55))) return rc;
     c->has_weights = true;
     return SRCNN_OK;
@@ -733,8 +883,9 @@ int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const fl
 /* Undocumented diagnostics hook (not part of the ABI): copy the scratch buffer to the host. */
 int srcnn_debug_read_sink(srcnn_ctx *c, void *dst, size_t bytes)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!dst || bytes > c->sink.cap) return SRCNN_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(dst, c->sink.p, bytes, hipMemcpyDeviceToHost));
@@ -750,8 +901,9 @@ extern "C" int srcnn_debug_plan_items(int n_cu, int n_strips, int row_begin, int
 {
     const ItemPlan plan = plan_items(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams != 0);
     if (plan.count() > max_items || plan.n_seams() > max_seams || !items || !seams || !n_seams) return SRCNN_ERR_INVALID;
-    std::memcpy(items, plan.items.data(), plan.items.size() * sizeof(int));
-    std::memcpy(seams, plan.seams.data(), plan.seams.size() * sizeof(int));
+    // an empty vector's data() may be null, which memcpy must not be given even for 0 bytes (found by UBSan)
+    if (!plan.items.empty()) std::memcpy(items, plan.items.data(), plan.items.size() * sizeof(int));
+    if (!plan.seams.empty()) std::memcpy(seams, plan.seams.data(), plan.seams.size() * sizeof(int));
     *n_seams = plan.n_seams();
     return plan.count();
 }
@@ -801,8 +953,9 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
 int srcnn_conv99x11_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, float *d_planes,
                         size_t plane_stride, size_t plane_pitch, int width, int height)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_planes, plane_stride, width, height) ||
         plane_pitch < plane_stride * (size_t)height)
@@ -829,8 +982,9 @@ int srcnn_conv99x11_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, f
 int srcnn_conv55_dev(srcnn_ctx *c, const float *d_planes, size_t plane_stride, size_t plane_pitch,
                      uint8_t *d_dst, size_t dst_stride, int width, int height, float *d_preclamp)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_planes, plane_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         plane_pitch < plane_stride * (size_t)height)
@@ -859,8 +1013,9 @@ int srcnn_forward_y_unfused_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_s
                                 uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch, int width,
                                 int height, int n_frames, float *d_work)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || !d_work ||
         n_frames <= 0)
@@ -907,12 +1062,17 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
                         uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch, int width, int height,
                         int n_frames, float *d_preclamp)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         n_frames <= 0)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: bad arguments");
+    // every output pixel reads a 13x13 input window that other workgroups may already have overwritten
+    if (ranges_overlap(d_src, span_elems(src_stride, src_frame_pitch, width, height, n_frames), d_dst,
+                       span_elems(dst_stride, dst_frame_pitch, width, height, n_frames)))
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: src and dst overlap (the path cannot run in place)");
     if (c->mode == SRCNN_MODE_EXACT) {
         // frame by frame through ONE 32-plane workspace (128 B/pixel), whatever the batch size
         const long pitch = (long)width * height;
@@ -948,8 +1108,9 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
                              uint8_t *d_dst, size_t dst_stride, int dst_row0, int width, int height,
                              int row_begin, int row_end)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         row_begin < 0 || row_end > height || row_begin >= row_end ||
@@ -978,8 +1139,9 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
 int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_stride, uint8_t *const *dst,
                            size_t dst_stride, int width, int height, int n_frames)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (!src || !dst || n_frames <= 0 || width <= 0 || height <= 0 || src_stride < (size_t)width ||
         dst_stride < (size_t)width)
@@ -1051,8 +1213,9 @@ int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_s
 int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t *dst, size_t dst_stride,
                     int width, int height, float *preclamp, size_t preclamp_stride)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) ||
         (preclamp && preclamp_stride < (size_t)width))
@@ -1080,22 +1243,23 @@ int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *
                     int width, int height, const float *kernel99, const float *bias99, const float *kernel11,
                     const float *bias11)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
     if (bad_plane(src, src_stride, width, height) || !dst || dst_stride < (size_t)width || !kernel99 ||
         !bias99 || !kernel11 || !bias11)
         return fail(c, SRCNN_ERR_INVALID, "conv99x11: bad arguments");
     for (int k = 0; k < 32; ++k)
         if (!dst[k]) return fail(c, SRCNN_ERR_INVALID, "conv99x11: null output plane %d", k);
-    // layers 1-2 of the model are replaced; layer 3 of any loaded model is kept
-    std::vector<float> w3(800, 0.f);
-    float b3 = c->b3;
-    if (c->has_weights) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(w3.data(), static_cast<float *>(c->wraw.p) + 7329, 800 * 4, hipMemcpyDeviceToHost));
+    // Layers 1-2 of the model are replaced, layer 3 of any loaded model is kept.  The reference passes the same
+    // const tables on every call (src/srcnn.cpp:609): tables equal to the uploaded ones are not packed again.
+    const float *hr = c->host_raw.data();
+    const bool same = c->has_weights && !std::memcmp(hr, bias99, 64 * 4) && !std::memcmp(hr + 64, kernel99, 5184 * 4) &&
+                      !std::memcmp(hr + 5248, bias11, 32 * 4) && !std::memcmp(hr + 5280, kernel11, 2048 * 4);
+    if (!same) {
+        const std::vector<float> w3(hr + 7329, hr + 8129);      // upload_weights rewrites host_raw
+        if ((rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), c->b3))) return rc;
+        c->has_weights = true;
     }
-    if ((rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), b3))) return rc;
-    c->has_weights = true;
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->in_u8, n))) return rc;
     if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
@@ -1104,39 +1268,31 @@ int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *
     rc = srcnn_conv99x11_dev(c, static_cast<uint8_t *>(c->in_u8.p), width, static_cast<float *>(c->planes.p),
                              width, n, width, height);
     if (rc) return rc;
-    for (int k = 0; k < 32; ++k)
-        HIP_TRY(c, hipMemcpy2DAsync(dst[k], dst_stride * 4, static_cast<float *>(c->planes.p) + n * k,
-                                    (size_t)width * 4, (size_t)width * 4, height, hipMemcpyDeviceToHost,
-                                    c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SRCNN_OK;
+    return planes_to_host(c, static_cast<const float *>(c->planes.p), n, dst, dst_stride, width, height, 32);
 }
 
 int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8_t *dst, size_t dst_stride,
                  int width, int height, const float *kernel, float bias)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
     if (!src || src_stride < (size_t)width || bad_plane(dst, dst_stride, width, height) || !kernel)
         return fail(c, SRCNN_ERR_INVALID, "conv55: bad arguments");
     for (int k = 0; k < 32; ++k)
         if (!src[k]) return fail(c, SRCNN_ERR_INVALID, "conv55: null input plane %d", k);
-    // layer 3 of the model is replaced; layers 1-2 of any loaded model are kept
-    std::vector<float> raw(8129, 0.f);
-    if (c->has_weights) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(raw.data(), c->wraw.p, 8129 * 4, hipMemcpyDeviceToHost));
+    // layer 3 of the model is replaced; layers 1-2 of any loaded model are kept (src/srcnn.cpp:627)
+    const float *hr = c->host_raw.data();
+    const bool same = c->has_weights && hr[7328] == bias && !std::memcmp(hr + 7329, kernel, 800 * 4);
+    if (!same) {
+        const std::vector<float> raw(c->host_raw);               // upload_weights rewrites host_raw
+        if ((rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias)))
+            return rc;
+        c->has_weights = true;
     }
-    if ((rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias)))
-        return rc;
-    c->has_weights = true;
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
     if ((rc = reserve(c, c->out_u8, n))) return rc;
-    for (int k = 0; k < 32; ++k)
-        HIP_TRY(c, hipMemcpy2DAsync(static_cast<float *>(c->planes.p) + n * k, (size_t)width * 4, src[k],
-                                    src_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice,
-                                    c->stream));
+    if ((rc = planes_from_host(c, src, src_stride, static_cast<float *>(c->planes.p), n, width, height, 32))) return rc;
     rc = srcnn_conv55_dev(c, static_cast<float *>(c->planes.p), width, n, static_cast<uint8_t *>(c->out_u8.p),
                           width, width, height, nullptr);
     if (rc) return rc;
@@ -1149,8 +1305,9 @@ int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8
 int srcnn_conv99(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *dst, size_t dst_stride, int width,
                  int height, const float *kernel, float bias)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) || !kernel)
         return fail(c, SRCNN_ERR_INVALID, "conv99: bad arguments");
     const size_t n = (size_t)width * height;
@@ -1171,8 +1328,9 @@ int srcnn_conv99(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *dst
 int srcnn_conv11(srcnn_ctx *c, const float *const *src, size_t src_stride, float *dst, size_t dst_stride,
                  int width, int height, const float *kernel, float bias)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!src || src_stride < (size_t)width || bad_plane(dst, dst_stride, width, height) || !kernel)
         return fail(c, SRCNN_ERR_INVALID, "conv11: bad arguments");
     for (int k = 0; k < 64; ++k)
@@ -1182,10 +1340,7 @@ int srcnn_conv11(srcnn_ctx *c, const float *const *src, size_t src_stride, float
     if ((rc = reserve(c, c->plane1, n * 4))) return rc;
     if ((rc = reserve(c, c->kern, 1024 * 4))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->kern.p, kernel, 64 * 4, hipMemcpyHostToDevice, c->stream));
-    for (int k = 0; k < 64; ++k)
-        HIP_TRY(c, hipMemcpy2DAsync(static_cast<float *>(c->planes.p) + n * k, (size_t)width * 4, src[k],
-                                    src_stride * 4, (size_t)width * 4, height, hipMemcpyHostToDevice,
-                                    c->stream));
+    if ((rc = planes_from_host(c, src, src_stride, static_cast<float *>(c->planes.p), n, width, height, 64))) return rc;
     HIP_TRY(c, launch_conv11_exact(static_cast<float *>(c->planes.p), width, (long)n,
                                    static_cast<float *>(c->plane1.p), width, width, height,
                                    static_cast<float *>(c->kern.p), bias, c->stream));
@@ -1208,8 +1363,9 @@ int srcnn_scaled_size(int width, int height, float scale, int *out_w, int *out_h
 int srcnn_bgr2ycrcb(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width, int height, uint8_t *y,
                     uint8_t *cr, uint8_t *cb, size_t plane_stride)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!bgr || !y || !cr || !cb || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
         plane_stride < (size_t)width)
         return fail(c, SRCNN_ERR_INVALID, "bgr2ycrcb: bad arguments");
@@ -1231,8 +1387,9 @@ int srcnn_bgr2ycrcb(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width, 
 int srcnn_ycrcb2bgr(srcnn_ctx *c, const uint8_t *y, const uint8_t *cr, const uint8_t *cb, size_t plane_stride,
                     int width, int height, uint8_t *bgr, size_t stride)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!bgr || !y || !cr || !cb || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
         plane_stride < (size_t)width)
         return fail(c, SRCNN_ERR_INVALID, "ycrcb2bgr: bad arguments");
@@ -1255,8 +1412,9 @@ int srcnn_ycrcb2bgr(srcnn_ctx *c, const uint8_t *y, const uint8_t *cr, const uin
 int srcnn_resize_cubic(srcnn_ctx *c, const uint8_t *src, size_t src_stride, int src_w, int src_h, uint8_t *dst,
                        size_t dst_stride, int dst_w, int dst_h)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (bad_plane(src, src_stride, src_w, src_h) || bad_plane(dst, dst_stride, dst_w, dst_h))
         return fail(c, SRCNN_ERR_INVALID, "resize_cubic: bad arguments");
     const size_t ns = (size_t)src_w * src_h, nd = (size_t)dst_w * dst_h;
@@ -1276,8 +1434,9 @@ int srcnn_resize_cubic(srcnn_ctx *c, const uint8_t *src, size_t src_stride, int 
 int srcnn_process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int width, int height, float scale,
                           uint8_t *d_out, size_t out_stride)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     int ow = 0, oh = 0;
     if (!d_bgr || !d_out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
@@ -1289,8 +1448,9 @@ int srcnn_process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int
 int srcnn_process_bgr(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width, int height, float scale,
                       uint8_t *out, size_t out_stride)
 {
-    int rc = bind(c);
-    if (rc) return rc;
+    BIND(c);
+    int rc = SRCNN_OK;
+    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     int ow = 0, oh = 0;
     if (!bgr || !out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
@@ -1306,6 +1466,246 @@ int srcnn_process_bgr(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width
     HIP_TRY(c, hipMemcpy2DAsync(out, out_stride, c->bgr_out.p, 3 * (size_t)ow, 3 * (size_t)ow, oh,
                                 hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+
+/* ------------------------- several GPUs from one host process ---------------- */
+
+int srcnn_stripe_rows(int height, int n_parts, int index, int *row_begin, int *row_end)
+{
+    if (height < 0 || n_parts <= 0 || index < 0 || index >= n_parts || !row_begin || !row_end) return SRCNN_ERR_INVALID;
+    const int base = height / n_parts, extra = height % n_parts;
+    *row_begin = index * base + std::min(index, extra);
+    *row_end = *row_begin + base + (index < extra ? 1 : 0);
+    return SRCNN_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+constexpr int kHalo = 6;       // 4 input rows of the 9x9 layer + 2 feature rows of the 5x5 layer
+
+int check_ctx_set(srcnn_ctx *const *ctxs, int n_ctx)
+{
+    if (!ctxs || n_ctx <= 0) return SRCNN_ERR_INVALID;
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k]) return SRCNN_ERR_INVALID;
+        if (!ctxs[k]->has_weights) return fail(ctxs[k], SRCNN_ERR_STATE, "srcnn_set_weights not called");
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(ctxs[k], SRCNN_ERR_INVALID, "the same context appears twice");
+    }
+    return SRCNN_OK;
+}
+
+// rows of a stripe held by another context (possibly on another device) -> this context's buffer, on `st`
+hipError_t copy_rows_between(srcnn_ctx *to, uint8_t *dst, size_t dst_stride, const srcnn_ctx *from, const uint8_t *src,
+                             size_t src_stride, int width, int rows, hipStream_t st)
+{
+    if (from->device == to->device)
+        return hipMemcpy2DAsync(dst, dst_stride, src, src_stride, (size_t)width, (size_t)rows, hipMemcpyDeviceToDevice, st);
+    if (dst_stride == (size_t)width && src_stride == (size_t)width)
+        return hipMemcpyPeerAsync(dst, to->device, src, from->device, (size_t)width * rows, st);
+    for (int r = 0; r < rows; ++r) {
+        const hipError_t e = hipMemcpyPeerAsync(dst + (size_t)r * dst_stride, to->device, src + (size_t)r * src_stride,
+                                                from->device, (size_t)width, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// One context's part of the striped step.  Runs on its own host thread (one thread per device).
+int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const *d_stripes, size_t stripe_stride,
+                 uint8_t *const *d_out, size_t out_stride, int width, int height)
+{
+    srcnn_ctx *c = ctxs[k];
+    BIND(c);
+    int rc, r0, r1, a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
+    const bool has_top = k > 0, has_bot = k < n_ctx - 1;
+    if (has_top) srcnn_stripe_rows(height, n_ctx, k - 1, &a0, &a1);
+    if (has_bot) srcnn_stripe_rows(height, n_ctx, k + 1, &b0, &b1);
+    if (!has_top && !has_bot)
+        return srcnn_forward_y_rows_dev(c, d_stripes[k], stripe_stride, 0, d_out[k], out_stride, 0, width, height, 0, height);
+    if (!c->halo_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->bands_done, hipEventDisableTiming));
+        for (int n : {k - 1, k + 1})                // direct xGMI copies where the link allows; staged otherwise
+            if (n >= 0 && n < n_ctx && ctxs[n]->device != c->device) {
+                (void)hipDeviceEnablePeerAccess(ctxs[n]->device, 0);
+                (void)hipGetLastError();
+            }
+    }
+    const size_t band_bytes = (size_t)3 * kHalo * width;
+    if ((rc = reserve(c, c->band_top, band_bytes))) return rc;
+    if ((rc = reserve(c, c->band_bot, band_bytes))) return rc;
+    uint8_t *top = static_cast<uint8_t *>(c->band_top.p), *bot = static_cast<uint8_t *>(c->band_bot.p);
+    const int rows = r1 - r0;
+    // the band inputs of the previous step may still be read by its band launches
+    if (c->bands_pending) HIP_TRY(c, hipStreamWaitEvent(c->halo_stream, c->bands_done, 0));
+    if (rows < 3 * kHalo) {
+        // stripe too thin to split: assemble [halo | stripe | halo] and launch once
+        const int s0 = has_top ? r0 - kHalo : r0, s1 = has_bot ? r1 + kHalo : r1;
+        if ((rc = reserve(c, c->stripe_ext, (size_t)(s1 - s0) * width))) return rc;
+        uint8_t *ext = static_cast<uint8_t *>(c->stripe_ext.p);
+        if (has_top)
+            HIP_TRY(c, copy_rows_between(c, ext, width, ctxs[k - 1], d_stripes[k - 1] + (size_t)(a1 - a0 - kHalo) * stripe_stride,
+                                         stripe_stride, width, kHalo, c->halo_stream));
+        HIP_TRY(c, hipMemcpy2DAsync(ext + (size_t)(r0 - s0) * width, width, d_stripes[k], stripe_stride, width, rows,
+                                    hipMemcpyDeviceToDevice, c->halo_stream));
+        if (has_bot)
+            HIP_TRY(c, copy_rows_between(c, ext + (size_t)(r1 - s0) * width, width, ctxs[k + 1], d_stripes[k + 1], stripe_stride,
+                                         width, kHalo, c->halo_stream));
+        HIP_TRY(c, hipEventRecord(c->halo_ready, c->halo_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->halo_ready, 0));
+        rc = srcnn_forward_y_rows_dev(c, ext, width, s0, d_out[k], out_stride, r0, width, height, r0, r1);
+        if (rc) return rc;
+        HIP_TRY(c, hipEventRecord(c->bands_done, c->stream));
+        c->bands_pending = true;
+        return SRCNN_OK;
+    }
+    // halo stream: [6 rows of the upper neighbour | my first 12 rows] and [my last 12 rows | 6 rows of the lower one]
+    if (has_top) {
+        HIP_TRY(c, copy_rows_between(c, top, width, ctxs[k - 1], d_stripes[k - 1] + (size_t)(a1 - a0 - kHalo) * stripe_stride,
+                                     stripe_stride, width, kHalo, c->halo_stream));
+        HIP_TRY(c, hipMemcpy2DAsync(top + (size_t)kHalo * width, width, d_stripes[k], stripe_stride, width, 2 * kHalo,
+                                    hipMemcpyDeviceToDevice, c->halo_stream));
+    }
+    if (has_bot) {
+        HIP_TRY(c, hipMemcpy2DAsync(bot, width, d_stripes[k] + (size_t)(rows - 2 * kHalo) * stripe_stride, stripe_stride, width,
+                                    2 * kHalo, hipMemcpyDeviceToDevice, c->halo_stream));
+        HIP_TRY(c, copy_rows_between(c, bot + (size_t)2 * kHalo * width, width, ctxs[k + 1], d_stripes[k + 1], stripe_stride,
+                                     width, kHalo, c->halo_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->halo_ready, c->halo_stream));
+    // main stream: the interior rows need no halo and run while the copies are in flight
+    const int i0 = has_top ? r0 + kHalo : r0, i1 = has_bot ? r1 - kHalo : r1;
+    if ((rc = srcnn_forward_y_rows_dev(c, d_stripes[k], stripe_stride, r0, d_out[k], out_stride, r0, width, height, i0, i1)))
+        return rc;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->halo_ready, 0));
+    if (has_top && (rc = srcnn_forward_y_rows_dev(c, top, width, r0 - kHalo, d_out[k], out_stride, r0, width, height, r0, i0)))
+        return rc;
+    if (has_bot && (rc = srcnn_forward_y_rows_dev(c, bot, width, r1 - 2 * kHalo, d_out[k], out_stride, r0, width, height, i1, r1)))
+        return rc;
+    HIP_TRY(c, hipEventRecord(c->bands_done, c->stream));
+    c->bands_pending = true;
+    return SRCNN_OK;
+}
+
+template <typename Fn>
+int run_per_context(int n_ctx, Fn fn)
+{
+    std::vector<int> rcs((size_t)n_ctx, SRCNN_OK);
+    std::vector<std::thread> pool;
+    for (int k = 1; k < n_ctx; ++k) pool.emplace_back([&rcs, &fn, k] { rcs[(size_t)k] = fn(k); });
+    rcs[0] = fn(0);
+    for (auto &t : pool) t.join();
+    for (int rc : rcs)
+        if (rc) return rc;
+    return SRCNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srcnn_forward_y_striped_dev(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *d_stripes, size_t stripe_stride,
+                                uint8_t *const *d_out, size_t out_stride, int width, int height)
+{
+    int rc = check_ctx_set(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!d_stripes || !d_out || width <= 0 || height <= 0 || stripe_stride < (size_t)width || out_stride < (size_t)width)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_dev: bad arguments");
+    if (n_ctx > 1 && height / n_ctx < kHalo)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_dev: %d rows over %d contexts leaves stripes thinner than the "
+                                                "%d-row halo", height, n_ctx, kHalo);
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!d_stripes[k] || !d_out[k]) return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_dev: null stripe %d", k);
+        if (ctxs[k]->mode == SRCNN_MODE_EXACT) return fail(ctxs[k], SRCNN_ERR_STATE, "row stripes are MFMA-mode only");
+    }
+    return run_per_context(n_ctx, [&](int k) {
+        return striped_step(ctxs, n_ctx, k, d_stripes, stripe_stride, d_out, out_stride, width, height);
+    });
+}
+
+int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *src, size_t src_stride, uint8_t *dst,
+                            size_t dst_stride, int width, int height)
+{
+    int rc = check_ctx_set(ctxs, n_ctx);
+    if (rc) return rc;
+    if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height))
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped: bad plane geometry");
+    if (n_ctx > 1 && height / n_ctx < kHalo)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped: stripes thinner than the %d-row halo", kHalo);
+    std::vector<const uint8_t *> d_in((size_t)n_ctx);
+    std::vector<uint8_t *> d_res((size_t)n_ctx);
+    // phase 1: every device receives ITS rows only (the halo rows then travel device to device)
+    rc = run_per_context(n_ctx, [&](int k) -> int {
+        srcnn_ctx *c = ctxs[k];
+        BIND(c);
+        int r, r0, r1;
+        srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
+        const size_t n = (size_t)(r1 - r0) * width;
+        if ((r = reserve(c, c->in_u8, n))) return r;
+        if ((r = reserve(c, c->out_u8, n))) return r;
+        HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src + (size_t)r0 * src_stride, src_stride, width, r1 - r0,
+                                    hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        d_in[(size_t)k] = static_cast<const uint8_t *>(c->in_u8.p);
+        d_res[(size_t)k] = static_cast<uint8_t *>(c->out_u8.p);
+        return SRCNN_OK;
+    });
+    if (rc) return rc;
+    // phase 2: halo copies + interior rows + edge bands, then each device returns its rows
+    return run_per_context(n_ctx, [&](int k) -> int {
+        srcnn_ctx *c = ctxs[k];
+        BIND(c);
+        int r, r0, r1;
+        srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
+        if ((r = striped_step(ctxs, n_ctx, k, d_in.data(), width, d_res.data(), width, width, height))) return r;
+        HIP_TRY(c, hipMemcpy2DAsync(dst + (size_t)r0 * dst_stride, dst_stride, c->out_u8.p, width, width, r1 - r0,
+                                    hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return SRCNN_OK;
+    });
+}
+
+int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *src, size_t src_stride,
+                                 uint8_t *const *dst, size_t dst_stride, int width, int height, int n_frames)
+{
+    int rc = check_ctx_set(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!src || !dst || n_frames <= 0 || width <= 0 || height <= 0 || src_stride < (size_t)width ||
+        dst_stride < (size_t)width)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_frames_multi: bad arguments");
+    // contiguous frame ranges, one host thread per context, no collective: frames are independent
+    return run_per_context(n_ctx, [&](int k) -> int {
+        int f0, f1;
+        srcnn_stripe_rows(n_frames, n_ctx, k, &f0, &f1);
+        if (f1 == f0) return SRCNN_OK;
+        return srcnn_forward_y_frames(ctxs[k], src + f0, src_stride, dst + f0, dst_stride, width, height, f1 - f0);
+    });
+}
+
+/* Undocumented test hooks (not part of the ABI, need no device): the host-side table builders. */
+int srcnn_debug_pack_fragments(const float *blob8129, float *frag /*[NFRAG*64]*/, uint8_t *frag16 /*S16_TABLE_BYTES*/,
+                               int *frag_floats, int *frag16_bytes)
+{
+    if (frag_floats) *frag_floats = NFRAG * 64;
+    if (frag16_bytes) *frag16_bytes = (int)S16_TABLE_BYTES;
+    if (!blob8129) return SRCNN_ERR_INVALID;
+    const float *b1 = blob8129, *w1 = blob8129 + 64, *b2 = blob8129 + 5248, *w2 = blob8129 + 5280, *w3 = blob8129 + 7329;
+    if (frag) pack_fragments(w1, b1, w2, b2, w3, frag);
+    if (frag16) pack_fragments16(w1, b1, w2, b2, w3, frag16);
+    return split16_range_ok(w1, b1, w2, b2, w3) ? 1 : 0;
+}
+
+int srcnn_debug_cubic_table(int n_src, int n_dst, int *ofs, short *coef)
+{
+    if (n_src <= 0 || n_dst <= 0 || !ofs || !coef) return SRCNN_ERR_INVALID;
+    cubic_table(n_src, n_dst, ofs, coef);
     return SRCNN_OK;
 }
 

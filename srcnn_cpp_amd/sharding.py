@@ -133,6 +133,96 @@ def gpu_compute_rows(ctx) -> Callable:
     return run
 
 
+def gpu_launch_rows(ctx) -> Callable:
+    """Asynchronous launch_rows(src, src_row0, out, dst_row0, height, row_begin, row_end) for GPU tensors
+    through the C ABI (srcnn_forward_y_rows_dev) on the context's stream -- no host synchronisation.
+    The context must launch on torch's current stream (see ``gpu_compute_rows``)."""
+    def run(src, src_row0, out, dst_row0, height, row_begin, row_end):
+        if not (src.is_cuda and out.is_cuda):
+            raise RuntimeError("the HIP path needs device tensors (no CPU fallback)")
+        ctx.forward_y_rows_dev(src.data_ptr(), src.stride(0), src_row0, out.data_ptr(), out.stride(0),
+                               dst_row0, src.shape[1], height, row_begin, row_end)
+    return run
+
+
+def band_plan(height: int, world: int, rank: int):
+    """Split of this rank's output rows [r0, r1) for the overlapped stripe step:
+    (interior [i0, i1), top band or None, bottom band or None).  The interior rows need only the rank's
+    own input rows; a band is the HALO_ROWS output rows next to a neighbour, which need its halo rows.
+    Returns None when the stripe is too thin to split (then: exchange first, one launch)."""
+    r0, r1 = stripe_rows(height, world, rank)
+    has_top, has_bot = rank > 0, rank < world - 1
+    i0 = r0 + HALO_ROWS if has_top else r0
+    i1 = r1 - HALO_ROWS if has_bot else r1
+    # a band reads 2 * HALO_ROWS own rows below (above) its HALO_ROWS output rows
+    if (has_top or has_bot) and (r1 - r0 < 3 * HALO_ROWS or i1 - i0 < 1):
+        return None
+    return (i0, i1), ((r0, r0 + HALO_ROWS) if has_top else None), ((r1 - HALO_ROWS, r1) if has_bot else None)
+
+
+def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,
+                           group=None, overlap: bool = True, via_host: bool = False):
+    """One row-striped step of ONE plane, asynchronous on the caller's stream.
+
+    stripe / out : uint8 tensors [r1-r0, W], this rank's rows of the input / output plane.
+    overlap      : post the 6-row point-to-point exchange, launch the INTERIOR rows (which need no halo)
+                   while it is in flight, then the two 6-row edge bands from [halo | 12 own rows] buffers;
+                   otherwise exchange first and launch once (``forward_striped``).  Same bytes either way:
+                   any partition of the rows computes the same plane (tests/test_sharding_gloo.py).
+    via_host     : stage the halo rows through host memory (gloo group; smoke tests on a shared GPU).
+    """
+    import torch
+    import torch.distributed as dist
+
+    r0, r1 = stripe_rows(height, world, rank)
+    plan = band_plan(height, world, rank) if (overlap and world > 1) else None
+    if world == 1:
+        launch_rows(stripe, 0, out, 0, height, 0, height)
+        return out
+    if plan is None:
+        if via_host:
+            ext, s0 = exchange_halo(stripe.cpu(), height, world, rank, group)
+            ext = ext.to(stripe.device)
+        else:
+            ext, s0 = exchange_halo(stripe, height, world, rank, group)
+        launch_rows(ext, s0, out, r0, height, r0, r1)
+        return out
+    (i0, i1), top, bot = plan
+    # band inputs: [6 halo rows | first 12 own rows] and [last 12 own rows | 6 halo rows]
+    dev = "cpu" if via_host else stripe.device
+    width = stripe.shape[1]
+    src = stripe.cpu() if via_host else stripe
+    ops, keep = [], []
+    top_buf = bot_buf = None
+    if top:
+        top_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
+        send = src[:HALO_ROWS].contiguous()
+        keep.append(send)
+        ops += [dist.P2POp(dist.irecv, top_buf[:HALO_ROWS], rank - 1, group),
+                dist.P2POp(dist.isend, send, rank - 1, group)]
+    if bot:
+        bot_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
+        send = src[-HALO_ROWS:].contiguous()
+        keep.append(send)
+        ops += [dist.P2POp(dist.isend, send, rank + 1, group),
+                dist.P2POp(dist.irecv, bot_buf[2 * HALO_ROWS:], rank + 1, group)]
+    reqs = dist.batch_isend_irecv(ops)
+    launch_rows(stripe, r0, out, r0, height, i0, i1)          # overlaps the exchange
+    if top:
+        top_buf[HALO_ROWS:] = src[:2 * HALO_ROWS]
+    if bot:
+        bot_buf[:2 * HALO_ROWS] = src[-2 * HALO_ROWS:]
+    for req in reqs:
+        req.wait()
+    if top:
+        tb = top_buf.to(stripe.device) if via_host else top_buf
+        launch_rows(tb, r0 - HALO_ROWS, out, r0, height, top[0], top[1])
+    if bot:
+        bb = bot_buf.to(stripe.device) if via_host else bot_buf
+        launch_rows(bb, r1 - 2 * HALO_ROWS, out, r0, height, bot[0], bot[1])
+    return out
+
+
 def gather_stripes(out, height: int, world: int, rank: int, dst: int = 0, group=None):
     """Collect the output stripes on `dst` (verification / file output only; the
     data path itself needs no collective).  Returns the full plane on dst, None elsewhere."""

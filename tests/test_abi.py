@@ -96,3 +96,53 @@ def test_exact_kernels_have_no_fused_multiply_add(tmp_path):
     for banned in ("v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_mad_f32", "v_pk_fma_f32", "v_fma_f64",
                    "v_fma_mix"):
         assert banned not in asm, banned
+
+
+class _NoCall:
+    """Stands in for the C library: the binding must reject a bad call BEFORE reaching the ABI."""
+    def __getattr__(self, name):
+        raise AssertionError(f"{name} reached the C ABI with mismatched planes")
+
+
+def _shell_context():
+    ctx = object.__new__(S.Context)           # no device needed: only the Python-side validation runs
+    ctx._lib, ctx._h = _NoCall(), None
+    return ctx
+
+
+def test_python_binding_rejects_mismatched_shapes():
+    """A dst / preclamp / plane smaller than the plane the dims are taken from would be overrun by the
+    device-to-host copies (the C side only sees pointers and one width x height)."""
+    ctx = _shell_context()
+    u8, f32 = (lambda h, w: np.zeros((h, w), np.uint8)), (lambda h, w: np.zeros((h, w), np.float32))
+    with pytest.raises(ValueError):
+        ctx.forward_y(u8(8, 8), dst=u8(4, 8))
+    with pytest.raises(ValueError):
+        ctx.forward_y(u8(8, 8), dst=u8(8, 8), preclamp=f32(8, 7))
+    with pytest.raises(ValueError):
+        ctx.conv99(u8(4, 8), f32(8, 8), np.zeros(81, np.float32), 0.0)
+    with pytest.raises(ValueError):
+        ctx.conv11([f32(4, 8)] * 64, f32(8, 8), np.zeros(64, np.float32), 0.0)
+    with pytest.raises(ValueError):
+        ctx.conv11([f32(8, 8)] * 63 + [f32(4, 8)], f32(8, 8), np.zeros(64, np.float32), 0.0)
+    with pytest.raises(ValueError):
+        ctx.conv55([f32(8, 4)] * 32, u8(8, 8), np.zeros(800, np.float32), 0.0)
+    with pytest.raises(ValueError):
+        ctx.conv99x11(u8(8, 8), [f32(8, 8)] * 31 + [f32(7, 8)], np.zeros(5184, np.float32), np.zeros(64, np.float32),
+                      np.zeros(2048, np.float32), np.zeros(32, np.float32))
+    with pytest.raises(ValueError):
+        ctx.conv99x11(u8(8, 8), [f32(6, 8)] * 32, np.zeros(5184, np.float32), np.zeros(64, np.float32),
+                      np.zeros(2048, np.float32), np.zeros(32, np.float32))
+    frames = np.zeros((3, 8, 8), np.uint8)
+    with pytest.raises(ValueError):
+        ctx.forward_y_frames(frames, out=np.zeros((2, 8, 8), np.uint8))
+    with pytest.raises(TypeError):
+        ctx.forward_y_frames(frames, out=np.zeros((3, 8, 8), np.float32))
+    with pytest.raises(ValueError):
+        ctx.forward_y_frames(frames, out=np.zeros((3, 8, 16), np.uint8)[:, :, ::2])
+    ro = np.zeros((3, 8, 8), np.uint8)
+    ro.flags.writeable = False
+    with pytest.raises(ValueError):
+        ctx.forward_y_frames(frames, out=ro)
+    with pytest.raises(ValueError):
+        ctx.forward_y_frames(np.zeros((0, 8, 8), np.uint8))

@@ -1,0 +1,143 @@
+"""N > 1 on the GPU box.  The gpurun box has ONE MI355X, so several ranks / contexts share it:
+that exercises the launcher, the sharding arithmetic, the halo copies and the stream ordering -- everything
+except the xGMI links themselves.
+
+* bench.py --gpus 2 starts its own two ranks (fresh child processes, the parent never touches the GPU) for both
+  workloads; the N-rank output must equal the 1-rank output bit for bit (crc32 of every plane);
+* the C ABI's multi-device entry points (srcnn_forward_y_striped[_dev], srcnn_forward_y_frames_multi) with 2-3
+  contexts on cuda:0 against the single-context result, from Python and from a plain C++ host
+  (tools/host_demo_multi.cpp)."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_batch, synth_luma
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", "3", "--warmup", "1",
+                        *map(str, args)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_two_ranks_frames_equal_one_rank():
+    """`python bench.py --gpus 2` as the README says it: rc 0, n_gpus 2, one frame per rank, no collective; the two
+    output planes are frames 0 and 1 of the stream, exactly what one rank computes for --frames 2."""
+    w, h = 1920, 1080
+    one = run_bench("--gpus", 1, "--frames", 2, "--width", w, "--height", h)
+    two = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--width", w, "--height", h)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and len(two["per_rank_ms_per_step"]) == 2
+    assert two["distributed"]["halo_transport"].startswith("none")
+    assert two["config"]["output_crc32"] == one["config"]["output_crc32"] and len(one["config"]["output_crc32"]) == 2
+    assert two["value"] > 0 and two["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_bench_two_ranks_stripe_equal_one_rank(overlap):
+    """configs[3] shape: one plane, two ranks, 6-row halo exchange; the stitched plane equals the 1-rank plane."""
+    w, h = 1920, 1080
+    one = run_bench("--gpus", 1, "--workload", "stripe", "--width", w, "--height", h)
+    two = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--workload", "stripe", "--width", w, "--height", h,
+                    *([] if overlap else ["--no-overlap"]))
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["distributed"]["halo_overlap"] is overlap
+    assert two["config"]["output_crc32"] == one["config"]["output_crc32"] and len(one["config"]["output_crc32"]) == 1
+    # ... and it is the plane the model of the kernel's arithmetic predicts
+    import zlib
+    m_out, _ = oracle.gpuorder_forward_y(synth_luma(w, h), S.load_weights())
+    assert one["config"]["output_crc32"] == [zlib.crc32(m_out.tobytes())]
+
+
+@pytest.fixture(scope="module")
+def ctx_pool(weights_blob):
+    ctxs = [S.Context(0) for _ in range(3)]
+    for c in ctxs:
+        c.set_weights_blob(weights_blob)
+    yield ctxs
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("n_ctx,w,h", [(2, 260, 90), (3, 260, 90), (3, 131, 20), (2, 3840, 2160), (3, 1000, 37)])
+def test_striped_over_contexts_equals_single_context(gpu_ctx, ctx_pool, n_ctx, w, h):
+    """srcnn_forward_y_striped: own rows per context, halo rows device to device, interior rows first, edge bands
+    after the copies (stripes thinner than 18 rows take the assemble-then-launch path) -- same bytes as one context."""
+    y = synth_luma(w, h, frame=4)
+    whole = gpu_ctx.forward_y(y)
+    got = S.forward_y_striped(ctx_pool[:n_ctx], y)
+    assert np.array_equal(got, whole)
+    # twice in a row: the band buffers of step 1 are reused by step 2 (ordered by events, not by a host wait)
+    y2 = synth_luma(w, h, frame=5)
+    assert np.array_equal(S.forward_y_striped(ctx_pool[:n_ctx], y2), gpu_ctx.forward_y(y2))
+
+
+def test_striped_dev_back_to_back(gpu_ctx, ctx_pool):
+    """Device-resident striped steps queued back to back without host synchronisation in between."""
+    import torch
+    w, h, n_ctx = 700, 210, 3
+    planes = [synth_luma(w, h, frame=f) for f in range(4)]
+    rows = [S.stripe_rows(h, n_ctx, k) for k in range(n_ctx)]
+    assert rows[0][0] == 0 and rows[-1][1] == h
+    d_in = [[torch.from_numpy(p[a:b].copy()).cuda() for (a, b) in rows] for p in planes]
+    d_out = [[torch.zeros_like(t) for t in step] for step in d_in]
+    torch.cuda.synchronize()
+    for step_in, step_out in zip(d_in, d_out):
+        S.forward_y_striped_dev(ctx_pool[:n_ctx], [t.data_ptr() for t in step_in], w, [t.data_ptr() for t in step_out], w, w, h)
+    for c in ctx_pool[:n_ctx]:
+        c.synchronize()
+    for p, step_out in zip(planes, d_out):
+        got = np.concatenate([t.cpu().numpy() for t in step_out], axis=0)
+        assert np.array_equal(got, gpu_ctx.forward_y(p))
+
+
+def test_frames_over_contexts_equal_single_context(gpu_ctx, ctx_pool):
+    w, h, n = 300, 77, 7
+    frames = synth_batch(w, h, n)
+    ref = gpu_ctx.forward_y_frames(frames)
+    for n_ctx in (2, 3):
+        assert np.array_equal(S.forward_y_frames_multi(ctx_pool[:n_ctx], frames), ref)
+    # more contexts than frames: the surplus contexts get an empty range
+    assert np.array_equal(S.forward_y_frames_multi(ctx_pool, frames[:2]), ref[:2])
+
+
+def test_multi_context_argument_errors(ctx_pool):
+    y = synth_luma(64, 10)
+    with pytest.raises(S.SrcnnError):
+        S.forward_y_striped(ctx_pool[:2], y)                       # 5-row stripes < 6-row halo
+    with pytest.raises(S.SrcnnError):
+        S.forward_y_striped([ctx_pool[0], ctx_pool[0]], synth_luma(64, 40))     # the same context twice
+    fresh = S.Context(0)
+    try:
+        with pytest.raises(S.SrcnnError):
+            S.forward_y_striped([ctx_pool[0], fresh], synth_luma(64, 40))       # no model in the second context
+    finally:
+        fresh.close()
+
+
+def test_cpp_host_with_several_contexts(tmp_path):
+    """tools/host_demo_multi.cpp: a plain C++ host owning two contexts on cuda:0 runs one plane row-striped and a
+    stream of frames through include/srcnn_amd.hpp; it compares both with its own single-context run bit for bit,
+    and the last frame must be the plane the model predicts."""
+    exe = tmp_path / "host_demo_multi"
+    subprocess.run(["g++", "-std=c++17", "-pthread", f"-I{ROOT / 'include'}", str(ROOT / "tools" / "host_demo_multi.cpp"),
+                    f"-L{ROOT / 'srcnn_cpp_amd'}", "-lsrcnn_amd", f"-Wl,-rpath,{ROOT / 'srcnn_cpp_amd'}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    w, h, n = 520, 130, 5
+    out_file = tmp_path / "out.u8"
+    res = subprocess.run([str(exe), str(S._WEIGHTS_PATH), str(w), str(h), str(n), str(out_file), "0", "0"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr + res.stdout
+    assert "on 2 contexts" in res.stdout
+    got = np.fromfile(out_file, np.uint8).reshape(h, w)
+    m_out, _ = oracle.gpuorder_forward_y(synth_luma(w, h, frame=n - 1), S.load_weights())
+    assert np.array_equal(got, m_out)

@@ -36,6 +36,18 @@ def _oracle_rows(blob):
     return run
 
 
+def _oracle_launch_rows(blob):
+    """launch_rows(src, src_row0, out, dst_row0, height, rb, re) with srcnn_forward_y_rows_dev semantics."""
+    import oracle
+
+    def run(src, src_row0, out, dst_row0, height, rb, re):
+        a, b = max(0, rb - 6), min(height, re + 6)          # the rows the entry point requires
+        assert src_row0 <= a and src_row0 + src.shape[0] >= b, "launch reads rows the caller did not provide"
+        res, _ = oracle.forward_y(src.numpy()[a - src_row0:b - src_row0], blob)
+        out[rb - dst_row0:re - dst_row0] = torch.from_numpy(res[rb - a:re - a])
+    return run
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,9 +64,16 @@ def _worker(rank, world, port, q):
         assert s0 == s0w and np.array_equal(ext.numpy(), plane[s0w:s1w]), "halo rows are not the neighbours' rows"
         out = sharding.forward_striped(mine, H, world, rank, _oracle_rows(blob))
         full = sharding.gather_stripes(out, H, world, rank)
+        # the overlapped step (interior rows first, edge bands after the exchange) and its one-launch form
+        outs = []
+        for overlap in (True, False):
+            o = torch.zeros_like(mine)
+            sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), overlap=overlap)
+            outs.append(sharding.gather_stripes(o, H, world, rank))
+        assert sharding.band_plan(H, world, rank) is not None
         if rank == 0:
             ref, _ = oracle.forward_y(plane, blob)
-            q.put(("ok", bool(np.array_equal(full.numpy(), ref))))
+            q.put(("ok", bool(np.array_equal(full.numpy(), ref)) and all(np.array_equal(o.numpy(), ref) for o in outs)))
         # frame sharding: the ranges tile the stream, nothing is exchanged
         a, b = sharding.frame_range(11, world, rank)
         t = torch.zeros(11, dtype=torch.int64)
@@ -96,6 +115,15 @@ def test_split_ranges():
     assert sharding.halo_extent(100, 95, 100) == (89, 100)
     with pytest.raises(ValueError):
         sharding.split_range(5, 0, 0)
+
+
+def test_band_plan():
+    # 2160 rows over 8 ranks: 270-row stripes; interior ranks keep 258 interior rows and two 6-row bands
+    assert sharding.band_plan(2160, 8, 0) == ((0, 264), None, (264, 270))
+    assert sharding.band_plan(2160, 8, 3) == ((816, 1074), (810, 816), (1074, 1080))
+    assert sharding.band_plan(2160, 8, 7) == ((1896, 2160), (1890, 1896), None)
+    assert sharding.band_plan(2160, 1, 0) == ((0, 2160), None, None)
+    assert sharding.band_plan(34, 2, 0) is None            # 17-row stripes: too thin to split
 
 
 def test_thin_stripes_are_rejected():

@@ -37,6 +37,12 @@ inline bool read_file(const std::string &path, std::vector<unsigned char> &out)
     return ok;
 }
 
+// Files are untrusted input: dimensions above these caps are rejected before any size arithmetic
+// (65,535 per side, 2^28 pixels: a 4-channel scanline buffer then stays below 2^31 bytes).
+constexpr uint32_t kMaxSide = 65535;
+constexpr uint64_t kMaxPixels = 1ull << 28;
+inline bool sane_dims(uint64_t w, uint64_t h) { return w > 0 && h > 0 && w <= kMaxSide && h <= kMaxSide && w * h <= kMaxPixels; }
+
 inline uint32_t be32(const unsigned char *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
 inline int paeth(int a, int b, int c)
@@ -53,13 +59,20 @@ inline bool decode_png(const std::vector<unsigned char> &d, Image &img)
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<unsigned char> idat, plte;
+    bool have_ihdr = false, first = true;
     while (pos + 12 <= d.size()) {
         const uint32_t len = be32(&d[pos]);
         const char *type = reinterpret_cast<const char *>(&d[pos + 4]);
-        if (pos + 12 + (size_t)len > d.size()) return false;
+        if ((size_t)len > d.size() - pos - 12) return false;
         const unsigned char *body = &d[pos + 8];
-        if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
+        const bool is_ihdr = !std::memcmp(type, "IHDR", 4);
+        if (first != is_ihdr) return false;             // IHDR is the first chunk and appears once
+        first = false;
+        if (is_ihdr) {
+            if (len != 13) return false;
             w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
+            if (!sane_dims(w, h)) return false;
+            have_ihdr = true;
         } else if (!std::memcmp(type, "PLTE", 4)) {
             plte.assign(body, body + len);
         } else if (!std::memcmp(type, "IDAT", 4)) {
@@ -69,7 +82,7 @@ inline bool decode_png(const std::vector<unsigned char> &d, Image &img)
         }
         pos += 12 + (size_t)len;
     }
-    if (!w || !h || depth != 8 || interlace != 0) return false;
+    if (!have_ihdr || depth != 8 || interlace != 0 || idat.empty()) return false;
     int ch;
     switch (ctype) {
     case 0: ch = 1; break;
@@ -126,20 +139,26 @@ inline bool decode_pnm(const std::vector<unsigned char> &d, Image &img)
     size_t pos = 2;
     long vals[3];
     for (int k = 0; k < 3; ++k) {
+        int digits = 0;
         for (;;) {
             while (pos < d.size() && std::isspace(d[pos])) ++pos;
             if (pos < d.size() && d[pos] == '#') { while (pos < d.size() && d[pos] != '\n') ++pos; continue; }
             break;
         }
         long v = 0; bool any = false;
-        while (pos < d.size() && d[pos] >= '0' && d[pos] <= '9') { v = v * 10 + (d[pos++] - '0'); any = true; }
+        while (pos < d.size() && d[pos] >= '0' && d[pos] <= '9') {
+            if (++digits > 6) return false;              // 65,535 has 5 digits: no overflow of `v` possible
+            v = v * 10 + (d[pos++] - '0');
+            any = true;
+        }
         if (!any) return false;
         vals[k] = v;
     }
+    if (pos >= d.size() || !std::isspace(d[pos])) return false;
     ++pos;   // single whitespace after maxval
-    if (vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255) return false;
+    if (vals[0] <= 0 || vals[1] <= 0 || vals[2] != 255 || !sane_dims((uint64_t)vals[0], (uint64_t)vals[1])) return false;
     const size_t n = (size_t)vals[0] * vals[1];
-    if (pos + n * ch > d.size()) return false;
+    if (n * ch > d.size() - pos) return false;
     img.width = (int)vals[0]; img.height = (int)vals[1];
     img.bgr.resize(n * 3);
     for (size_t i = 0; i < n; ++i) {
