@@ -72,6 +72,7 @@ def lib() -> C.CDLL:
         _lib.opencv_bgr2ycrcb.argtypes = [_u8p, sz, i, i, _u8p, _u8p, _u8p, sz]
         _lib.opencv_ycrcb2bgr.argtypes = [_u8p, _u8p, _u8p, sz, i, i, _u8p, sz]
         _lib.opencv_resize_cubic.argtypes = [_u8p, sz, i, i, _u8p, sz, i, i]
+        _lib.opencv_resize_cubic_variant.argtypes = [_u8p, sz, i, i, _u8p, sz, i, i, i]
         _lib.opencv_scaled_dim.argtypes = [i, C.c_float]
     return _lib
 
@@ -234,11 +235,17 @@ def ycrcb2bgr(y, cr, cb):
     return out
 
 
-def resize_cubic(src, dst_w, dst_h):
+VERTICAL_SIMD_FLOAT, VERTICAL_FIXED, VERTICAL_FLOAT_FMA = 0, 1, 2
+
+
+def resize_cubic(src, dst_w, dst_h, vertical=VERTICAL_SIMD_FLOAT):
+    """cv::resize(INTER_CUBIC) of one 8-bit plane; ``vertical`` picks the vertical-pass arithmetic
+    (opencv_steps.c header): the x86 baseline build's float SIMD functor (the variant of record, which
+    reproduces the reference's picture exactly), the all-scalar fixed-point pass, or a float pass with FMA."""
     src, ps = _u8(src)
     h, w = src.shape
     out = np.empty((dst_h, dst_w), np.uint8)
-    rc = lib().opencv_resize_cubic(ps, w, w, h, out.ctypes.data_as(_u8p), dst_w, dst_w, dst_h)
+    rc = lib().opencv_resize_cubic_variant(ps, w, w, h, out.ctypes.data_as(_u8p), dst_w, dst_w, dst_h, int(vertical))
     assert rc == 0
     return out
 
@@ -247,12 +254,12 @@ def scaled_size(w, h, scale):
     return lib().opencv_scaled_dim(w, float(scale)), lib().opencv_scaled_dim(h, float(scale))
 
 
-def process_bgr(bgr, scale, blob, y_path=None):
+def process_bgr(bgr, scale, blob, y_path=None, vertical=VERTICAL_SIMD_FLOAT):
     """The reference's timed pipeline region (src/srcnn.cpp:505-659) on the CPU:
     colour conversion, 3 x bicubic, conv path on Y (``y_path`` defaults to the
     reference arithmetic ``forward_y``), conversion back."""
     h, w, _ = bgr.shape
     ow, oh = scaled_size(w, h, scale)
-    planes = [resize_cubic(p, ow, oh) for p in bgr2ycrcb(bgr)]
+    planes = [resize_cubic(p, ow, oh, vertical) for p in bgr2ycrcb(bgr)]
     y_sr, _ = (y_path or forward_y)(planes[0], blob)
     return ycrcb2bgr(y_sr, planes[1], planes[2])

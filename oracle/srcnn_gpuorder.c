@@ -9,11 +9,14 @@
  * srcnn_oracle.c (strict multiply-then-add) within the stated tolerance.
  *
  * Differences from the reference order (src/srcnn.cpp:288-321, :218-240):
- *   layers 1+2  same summation order (taps i-major/j-minor, then bias; input
- *               channels ascending, then bias), but every multiply-add is ONE
- *               fused multiply-add: v_mfma_f32_32x32x2_f32 is bit-for-bit a
- *               k-ordered fmaf chain.  The layer-1 bias enters as a 82nd
- *               "tap" (x = 1.0), i.e. fmaf(b, 1, t) == t + b rounded once.
+ *   layers 1+2  same summation order (layer 1: taps i-major/j-minor, then bias;
+ *               layer 2: the chain STARTS from the bias -- it is the MFMA's
+ *               initial accumulator -- then input channels ascending), and
+ *               every multiply-add is ONE fused multiply-add:
+ *               v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain.
+ *               The layer-1 bias enters as a 82nd "tap" (x = 1.0), i.e.
+ *               fmaf(b, 1, t) == t + b rounded once.  (The kernels scale both
+ *               layers by exact powers of two; that changes no bit.)
  *   layer 3     the 5x5x32 contraction is split as  T[tap] = sum_c W3[c][tap]*F[c]
  *               (fmaf chain, channels ascending, float) per FEATURE pixel,
  *               followed by a float shifted sum of the 25 tap planes, tap
@@ -50,9 +53,8 @@ int srcnn_gpuorder_conv99x11(const uint8_t *src, size_t sstride, float *const *d
                 t[k] = a < 0 ? 0 : a;
             }
             for (int k = 0; k < 32; k++) {
-                float r = 0.f;
+                float r = bias11[k];                  /* the MFMA chain starts from the bias */
                 for (int i = 0; i < 64; i++) r = fmaf(kernel11[k * 64 + i], t[i], r);
-                r = r + bias11[k];
                 dst[k][(size_t)row * dstride + col] = r < 0 ? 0 : r;
             }
         }

@@ -18,10 +18,14 @@ OBJ = PKG.parent / "build"
 
 ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+if os.environ.get("SRCNN_ABLATION_BUILD"):      # timing-only ablation kernels (profiles/rNN/ablation.txt); never shipped
+    COMMON.append("-DSRCNN_ABLATION_BUILD")
 # (source, extra flags).  srcnn_exact.hip reproduces the reference's
 # multiply-then-add arithmetic: contraction to FMA must stay off there.
 UNITS = [
-    ("srcnn_mfma.hip", []),
+    # the SLP vectoriser packs the few scalar adds of the layer-3 sums into v_pk_add_f32 behind v_mov shuffles: more
+    # vector instructions, not fewer, and every one of them costs MFMA issue time
+    ("srcnn_mfma.hip", ["-fno-slp-vectorize"]),
     # MFMA results are consumed by vector instructions: keep them in architectural VGPRs (the 1-wave/SIMD
     # variant pins its weight fragments to AGPRs instead)
     ("srcnn_split16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),

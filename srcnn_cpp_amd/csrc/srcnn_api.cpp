@@ -159,29 +159,67 @@ void release(DevBuf &b)
     b.cap = 0;
 }
 
+// Smallest e with  bound * (1 + 2^-16) <= 2^e  (0 for a zero / non-finite bound).
+int scale_exponent(double bound)
+{
+    if (!(bound > 0.0) || !std::isfinite(bound)) return 0;
+    int e = 0;
+    (void)std::frexp(bound * (1.0 + 1.0 / 65536.0), &e);      // bound' = m * 2^e, m in [0.5, 1)  ->  bound' < 2^e
+    return e;
+}
+
+// Power-of-two scales of layers 1 and 2 (srcnn_kernels.h): rigorous bounds of the two maps for ANY 8-bit input --
+// layer-1 channel c is at most 255 * sum(max(w1, 0)) + b1, layer-2 channel k at most sum(max(w2, 0) * bound1) + b2.
+void layer_scales(const float *w1, const float *b1, const float *w2, const float *b2, int *e1, int *e2)
+{
+    double a1[64], m1 = 0.0, m2 = 0.0;
+    for (int c = 0; c < 64; ++c) {
+        double s = 0.0;
+        for (int t = 0; t < 81; ++t) s += std::max(w1[c * 81 + t], 0.f);
+        a1[c] = std::max(0.0, 255.0 * s + b1[c]);
+        m1 = std::max(m1, a1[c]);
+    }
+    for (int k = 0; k < 32; ++k) {
+        double s = b2[k];
+        for (int i = 0; i < 64; ++i) s += (double)std::max(w2[k * 64 + i], 0.f) * a1[i];
+        m2 = std::max(m2, s);
+    }
+    *e1 = scale_exponent(m1);
+    *e2 = scale_exponent(m2);
+}
+
 // Pack the reference-layout weights into per-lane MFMA A-operand fragments.
 // Fragment q, lane l: i = l & 31 is the accumulator row the lane's weight
 // feeds, kk = l >> 5 the k-slot (see srcnn_mfma.hip header).
 void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *w2 /*[32][64]*/,
                     const float *b2, const float *w3 /*[32][25]*/, float *out /*[NFRAG][64]*/)
 {
+    int e1, e2;
+    layer_scales(w1, b1, w2, b2, &e1, &e2);
     for (int l = 0; l < 64; ++l) {
         const int i = l & 31, kk = l >> 5;
         const int ch = row_chan(i);
         for (int t = 0; t < 2; ++t)
             for (int s = 0; s < 41; ++s) {
                 const int tap = 2 * s + kk, c = 32 * t + ch;
-                out[(t * 41 + s) * 64 + l] = tap < 81 ? w1[c * 81 + tap] : b1[c];
+                out[(t * 41 + s) * 64 + l] = std::ldexp(tap < 81 ? w1[c * 81 + tap] : b1[c], -e1);
             }
         for (int t = 0; t < 2; ++t)
-            for (int r = 0; r < 16; ++r)
-                out[(NFRAG_L1 + t * 16 + r) * 64 + l] = w2[ch * 64 + 32 * t + 2 * r + kk];
+            for (int r = 0; r < 16; ++r) {
+                const float w = w2[ch * 64 + 32 * t + 2 * r + kk];
+                out[(FRAG_L2 + t * 16 + r) * 64 + l] = std::ldexp(w, e1 - e2);
+                out[(FRAG_L2U + t * 16 + r) * 64 + l] = std::ldexp(w, e1);
+            }
         for (int r = 0; r < 16; ++r) {
             const int tap = l3_row_tap(i);
-            out[(NFRAG_L1 + NFRAG_L2 + r) * 64 + l] = tap >= 0 ? w3[(2 * r + kk) * 25 + tap] : 0.f;
+            const float w = tap >= 0 ? w3[(2 * r + kk) * 25 + tap] : 0.f;
+            out[(FRAG_L3 + r) * 64 + l] = std::ldexp(w, e2);
+            out[(FRAG_L3U + r) * 64 + l] = w;
         }
-        for (int r = 0; r < 16; ++r)
-            out[(NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + r) * 64 + l] = b2[2 * r + kk];
+        for (int r = 0; r < 16; ++r) {
+            out[(FRAG_B2 + r) * 64 + l] = std::ldexp(b2[2 * r + kk], -e2);
+            out[(FRAG_B2U + r) * 64 + l] = b2[2 * r + kk];
+        }
     }
 }
 

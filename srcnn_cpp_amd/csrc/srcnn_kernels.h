@@ -17,11 +17,20 @@ constexpr int NTHREADS = NWAVES * 64;
 enum StripMode { MODE_FUSED = 0, MODE_L12 = 1, MODE_L3 = 2 };
 
 // Packed MFMA A-operand fragments, [NFRAG][64 lanes] floats (see pack_fragments()).
-constexpr int NFRAG_L1 = 82;       // 2 channel tiles x 41 k-steps (81 taps + bias tap)
-constexpr int NFRAG_L2 = 32;       // 2 x 16 k-steps over the 64 layer-1 channels
-constexpr int NFRAG_L3 = 16;       // 16 k-steps over the 32 layer-2 channels, rows = 25 taps (+7 zero), see l3_row_tap()
-constexpr int NFRAG_B2 = 16;       // layer-2 bias laid out like the accumulator
-constexpr int NFRAG = NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + NFRAG_B2;
+// The layers are SCALED by exact powers of two so that every activation lies in [-1, 1] for any 8-bit input
+// (layer 1 by 2^-e1, layer 2 by 2^-e2; pack_fragments() derives e1, e2 from the weights): ReLU is then the clamp
+// bit of a packed multiply by 1.0 -- one instruction per TWO registers -- and the scaling changes no result bit
+// (a power-of-two factor commutes with every rounding; the layer-3 weights carry 2^e2 back).
+constexpr int NFRAG_L1 = 82;       // 2 channel tiles x 41 k-steps (81 taps + bias tap), x 2^-e1
+constexpr int NFRAG_L2 = 32;       // 2 x 16 k-steps over the 64 layer-1 channels, x 2^(e1-e2)        (MODE_FUSED)
+constexpr int NFRAG_L3 = 16;       // 16 k-steps over the 32 layer-2 channels, rows = 25 taps (+7 zero), x 2^e2 (MODE_FUSED)
+constexpr int NFRAG_B2 = 16;       // layer-2 bias laid out like the accumulator (the MFMA chain starts from it), x 2^-e2
+constexpr int NFRAG_L2U = 32;      // layer 2 with UNSCALED output, x 2^e1: MODE_L12 stores the reference's map
+constexpr int NFRAG_B2U = 16;      // ... and its unscaled bias
+constexpr int NFRAG_L3U = 16;      // layer 3 on the unscaled map from HBM (MODE_L3)
+constexpr int FRAG_L2 = NFRAG_L1, FRAG_L3 = FRAG_L2 + NFRAG_L2, FRAG_B2 = FRAG_L3 + NFRAG_L3,
+              FRAG_L2U = FRAG_B2 + NFRAG_B2, FRAG_B2U = FRAG_L2U + NFRAG_L2U, FRAG_L3U = FRAG_B2U + NFRAG_B2U;
+constexpr int NFRAG = FRAG_L3U + NFRAG_L3U;
 
 // MFMA 32x32 accumulator row held by register r on lane-half h, and the
 // channel we ASSIGN to accumulator row i so that register r / half h holds

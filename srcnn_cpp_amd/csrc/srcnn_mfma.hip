@@ -57,6 +57,7 @@
 namespace srcnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -119,7 +120,24 @@ __device__ __forceinline__ void cseam_export(const float *tile, float *dst, int 
     if (cl.cnt > 0) dst[e] = v;
 }
 
-template <int MODE, bool PRE, bool DIAG = false>
+// ReLU of TWO registers in one instruction.  The host scales layers 1 and 2 by exact powers of two so that every
+// activation is <= 1 for any 8-bit input (srcnn_kernels.h); v_pk_mul_f32 by 1.0 with the clamp bit then returns
+// min(max(x, 0), 1) = max(x, 0), the reference's (x < 0) ? 0 : x (src/srcnn.cpp:304,319).
+__device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        f32x2 pr = {a[2 * q], a[2 * q + 1]};
+        asm("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(pr) : "s"(ones));
+        a[2 * q] = pr.x;
+        a[2 * q + 1] = pr.y;
+    }
+}
+
+// ABL != 0: timing-only ablation builds (WRONG results by construction; SRCNN_DEBUG_TUNE bits 8..12 select one,
+// profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
+// instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS.
+template <int MODE, bool PRE, bool DIAG = false, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,21 +206,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 
     // ---- weight fragments -> registers (A operands, one VGPR per k-step) ----
     const float *wf = p.wfrag + lane;
-    float w1f[2][41], w2f[32], w3f[16], b2f[16];
+    float w1f[2][41], w2f[32], w3f[16];
+    f32x16 b2v = {0};
     if constexpr (MODE != MODE_L3) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int s = 0; s < 41; ++s) w1f[t][s] = wf[(t * 41 + s) * 64];
+        // MODE_FUSED keeps layer 2 scaled (ReLU by clamp); MODE_L12 stores the reference's unscaled map
+        constexpr int L2 = (MODE == MODE_L12) ? FRAG_L2U : FRAG_L2, B2 = (MODE == MODE_L12) ? FRAG_B2U : FRAG_B2;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) w2f[q] = wf[(NFRAG_L1 + q) * 64];
+        for (int q = 0; q < 32; ++q) w2f[q] = wf[(L2 + q) * 64];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) b2f[q] = wf[(NFRAG_L1 + NFRAG_L2 + NFRAG_L3 + q) * 64];
+        for (int q = 0; q < 16; ++q) b2v[q] = wf[(B2 + q) * 64];
     }
     if constexpr (MODE != MODE_L12) {
+        constexpr int L3 = (MODE == MODE_L3) ? FRAG_L3U : FRAG_L3;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) w3f[q] = wf[(NFRAG_L1 + NFRAG_L2 + q) * 64];
+        for (int q = 0; q < 16; ++q) w3f[q] = wf[(L3 + q) * 64];
     }
+    const f32x2 ones = {1.0f, 1.0f};
 
     // ---- layer-1 input: rolling window of Y rows as f32 in LDS --------------
     // Row r lives in slot r&15 AND in slot (r&15)+16, so the 9-row window that
@@ -388,13 +411,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             // (kept as the raw byte until after the MFMA stream: converting it
             // here would make the compiler wait for the load right away)
             unsigned ynext = 0;
-            if (tid < YP) ynext = load_y(f + 5);
+            if constexpr (!(ABL & 8))
+                if (tid < YP) ynext = load_y(f + 5);
 
             // ---------------- layer 1: 82 MFMA ------------------------------
             const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
             const float *ybN = yb + half;                    // taps 2s | 2s+1 in one row
             const float *ybW = yb + (half ? YP - 8 : 0);     // tap 2s = (ki,8), tap 2s+1 = (ki+1,0)
+            float abl_b = 1.0f;
+            if constexpr (ABL & 16) asm volatile("" : "+v"(abl_b));
             auto ldb = [&](int s) -> float {
+                if constexpr (ABL & 16) return abl_b;
                 const int ki = (2 * s) / 9, kj = (2 * s) % 9;
                 if (s == 40) return half ? 1.0f : yb[8 * YP + 8];   // tap 80 | bias tap
                 if (kj == 8) return ybW[ki * YP + kj];
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 #pragma unroll
                 for (int s = 0; s < 41; ++s) {
                     if (s + PF < 41) bq[s + PF] = ldb(s + PF);
-                    if constexpr (PB && MODE != MODE_L12) {
+                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2)) {
                         if (s == 2) hp_load(g, 0);
                         if (s == 8) hp_use(g, 0);
                     }
@@ -427,25 +454,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
             // dependent MFMAs breaks their back-to-back issue (~64 -> ~81 cycles per MFMA,
             // tools/mfma_probe.hip), 32 of them up front cost ~140 cycles once.
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a0[r] = relu(a0[r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] = relu(a1[r]);
+            if constexpr (!(ABL & 4)) {
+                relu_pairs(a0, ones);
+                relu_pairs(a1, ones);
+            }
             __builtin_amdgcn_sched_barrier(0);
 
-            // ---------------- layer 2: 32 MFMA, one back-to-back chain -------
-            d2 = (f32x16){0};
+            // ---------------- layer 2: 32 MFMA, one back-to-back chain that starts from the bias ------------
+            d2 = MFMA(w2f[0], a0[0], b2v);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[r], a0[r], d2);
+            for (int r = 1; r < 16; ++r) d2 = MFMA(w2f[r], a0[r], d2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[16 + r], a1[r], d2);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 4)) {
+                if constexpr (MODE == MODE_L12) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d2[r] = relu(d2[r] + b2f[r]);
+                    for (int r = 0; r < 16; ++r) d2[r] = relu(d2[r]);
+                } else {
+                    relu_pairs(d2, ones);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 
             asm volatile("" : "+v"(ynext));
-            if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
+            if constexpr (!(ABL & 8))
+                if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
 
             if constexpr (MODE == MODE_L12) {
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
@@ -470,11 +504,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
             __builtin_amdgcn_sched_barrier(0);
-            vertical(f, t);
+            if constexpr (ABL & 2) asm volatile("" ::"v"(t));
+            else vertical(f, t);
         }
 
         if constexpr (DIAG) dg_d = stamp();
-        lds_barrier();
+        if constexpr (!(ABL & 1)) lds_barrier();
         if constexpr (DIAG) {
             const unsigned long long e = stamp();
             dg_top += dg_b - dg_a;
@@ -631,6 +666,15 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
     switch (mode) {
     case MODE_FUSED:
         if (p.tune & 2) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, true>), grid, block, lds, stream, p);
+#ifdef SRCNN_ABLATION_BUILD
+#define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, false, n>), grid, block, lds, stream, p); break;
+        else if ((p.tune >> 8) & 31) {
+            switch ((p.tune >> 8) & 31) {
+                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31)
+            default: return hipErrorInvalidValue;
+            }
+        }
+#endif
         else if (pre) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false>), grid, block, lds, stream, p);
         break;

@@ -45,8 +45,29 @@ __global__ __launch_bounds__(256) void ycrcb2bgr_kernel(const uint8_t *__restric
     p[2] = sat8(Y + descale14(Cr * 22987));
 }
 
-// dst(dy,dx) = sat(( sum_ky beta[dy][ky] * sum_kx alpha[dx][kx] * src[clamp(yofs[dy]-1+ky)][clamp(xofs[dx]-1+kx)]
-//                    + 2^21 ) >> 22);   blockIdx.z = plane
+// Vertical pass of cv::resize(INTER_CUBIC), 8-bit (OpenCV 4.x modules/imgproc/src/resize.cpp, x86 baseline build).
+// h0..h3 are the int sums of the horizontal pass for the four source rows, b0..b3 the 11-bit row coefficients.
+// Columns below dw - dw % 8 go through the SIMD functor VResizeCubicVec_32s8u, which works in float32:
+//   r = h3*(b3*2^-22);  r = h2*(b2*2^-22) + r;  r = h1*(b1*2^-22) + r;  r = h0*(b0*2^-22) + r
+// with every product and every sum rounded on its own (the SSE baseline's v_muladd is mul + add: no contraction
+// here either), then round-to-nearest-even and saturate; the remaining dw % 8 columns take the scalar fixed-point
+// cast (sum + 2^21) >> 22.  This is the variant that reproduces the reference's published picture bit for bit
+// (oracle/opencv_steps.c, tests/test_pipeline_oracle.py).
+__device__ __forceinline__ unsigned vresize_px(int h0, int h1, int h2, int h3, int b0, int b1, int b2, int b3, bool simd)
+{
+    if (simd) {
+        const float sc = 1.0f / (2048.0f * 2048.0f);
+        float r = __fmul_rn((float)h3, (float)b3 * sc);
+        r = __fadd_rn(__fmul_rn((float)h2, (float)b2 * sc), r);
+        r = __fadd_rn(__fmul_rn((float)h1, (float)b1 * sc), r);
+        r = __fadd_rn(__fmul_rn((float)h0, (float)b0 * sc), r);
+        return sat8(__float2int_rn(r));
+    }
+    return sat8((h0 * b0 + h1 * b1 + h2 * b2 + h3 * b3 + (1 << 21)) >> 22);
+}
+
+// dst(dy,dx) = vresize_px( sum_kx alpha[dx][kx] * src[clamp(yofs[dy]-1+ky)][clamp(xofs[dx]-1+kx)], beta[dy][ky] );
+// blockIdx.z = plane
 __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t *__restrict__ src, long sstride, long spitch,
                                                            int sw, int sh, uint8_t *__restrict__ dst, long dstride,
                                                            long dpitch, int dw, int dh,
@@ -63,16 +84,18 @@ __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t *__rest
         a[k] = alpha[4 * dx + k];
         xs[k] = min(max(x0 + k, 0), sw - 1);
     }
-    int acc = 0;
+    int hs[4];
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
         const uint8_t *row = s + (long)min(max(y0 + ky, 0), sh - 1) * sstride;
         int t = 0;
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) t += row[xs[kx]] * a[kx];
-        acc += t * (int)beta[4 * dy + ky];
+        hs[ky] = t;
     }
-    dst[(long)blockIdx.z * dpitch + (long)dy * dstride + dx] = sat8((acc + (1 << 21)) >> 22);
+    const short *b = beta + 4 * dy;
+    dst[(long)blockIdx.z * dpitch + (long)dy * dstride + dx] =
+        (uint8_t)vresize_px(hs[0], hs[1], hs[2], hs[3], b[0], b[1], b[2], b[3], dx < dw - dw % 8);
 }
 
 // Tiled variant for up-scaling (and mild down-scaling): a workgroup produces RT output rows x 256
@@ -120,17 +143,17 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled_kernel(const uint8_t *
     if (dx >= dw) return;
     for (int dy = dy0; dy < dy1; ++dy) {
         const int j = yofs[dy] - 1 - r_lo;
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc += hbuf[j + k][threadIdx.x] * (int)beta[4 * dy + k];
-        dst[(long)blockIdx.z * dpitch + (long)dy * dstride + dx] = sat8((acc + (1 << 21)) >> 22);
+        const short *b = beta + 4 * dy;
+        dst[(long)blockIdx.z * dpitch + (long)dy * dstride + dx] =
+            (uint8_t)vresize_px(hbuf[j][threadIdx.x], hbuf[j + 1][threadIdx.x], hbuf[j + 2][threadIdx.x],
+                                hbuf[j + 3][threadIdx.x], b[0], b[1], b[2], b[3], dx < dw - dw % 8);
     }
 }
 
 // Second tiling: a workgroup produces a 256 x 32 output tile and every thread FOUR adjacent pixels of 8 rows, so
 // the vertical pass reads its taps as one 16-byte LDS word per row and stores one dword per row: a quarter of the
 // store and LDS instructions of the kernel above (which remains the fallback for small scales / odd strides).
-// Same integer arithmetic, bit-identical results.
+// Same arithmetic, bit-identical results.
 constexpr int RT4 = 32;       // output rows per workgroup
 constexpr int RMAX4 = 28;     // source rows such a tile may span (host checks)
 
@@ -180,16 +203,15 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t 
         const int dy = dy0 + 8 * ty + r;
         if (dy >= dy1) break;
         const int j = yofs[dy] - 1 - r_lo;
-        i32x4 acc = {0, 0, 0, 0};
+        i32x4 h[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const i32x4 h = *reinterpret_cast<const i32x4 *>(&hbuf[j + k][4 * tx]);
-            acc += h * (int)beta[4 * dy + k];
-        }
+        for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const i32x4 *>(&hbuf[j + k][4 * tx]);
+        const short *b = beta + 4 * dy;
         uint8_t *o = dst + (long)blockIdx.z * dpitch + (long)dy * dstride + dx;
         unsigned px[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) px[c] = sat8((acc[c] + (1 << 21)) >> 22);
+        for (int c = 0; c < 4; ++c)
+            px[c] = vresize_px(h[0][c], h[1][c], h[2][c], h[3][c], b[0], b[1], b[2], b[3], dx + c < dw - dw % 8);
         if (vec_ok) {
             *reinterpret_cast<unsigned *>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
         } else {

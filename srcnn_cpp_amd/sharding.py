@@ -98,6 +98,40 @@ def exchange_halo(stripe, height: int, world: int, rank: int, group=None):
     return ext, s0
 
 
+def exchange_halo_via_host(stripe, height: int, world: int, rank: int, group=None):
+    """``exchange_halo`` for a DEVICE stripe over a host-memory transport (gloo): only the 6-row halos are
+    staged through the host, the extended stripe is assembled on the device."""
+    import torch
+    import torch.distributed as dist
+
+    r0, r1 = stripe_rows(height, world, rank)
+    if world > 1 and min(stripe_rows(height, world, k)[1] - stripe_rows(height, world, k)[0]
+                         for k in range(world)) < HALO_ROWS:
+        raise ValueError("stripes thinner than the halo: use fewer ranks for this plane")
+    s0, s1 = halo_extent(height, r0, r1)
+    top_n, bot_n = r0 - s0, s1 - r1
+    ext = torch.empty((s1 - s0, stripe.shape[1]), dtype=stripe.dtype, device=stripe.device)
+    ext[top_n:top_n + (r1 - r0)] = stripe
+    ops, keep = [], []
+    recv_top = recv_bot = None
+    if top_n:
+        recv_top = torch.empty((top_n, stripe.shape[1]), dtype=stripe.dtype)
+        keep.append(stripe[:HALO_ROWS].cpu().contiguous())
+        ops += [dist.P2POp(dist.irecv, recv_top, rank - 1, group), dist.P2POp(dist.isend, keep[-1], rank - 1, group)]
+    if bot_n:
+        recv_bot = torch.empty((bot_n, stripe.shape[1]), dtype=stripe.dtype)
+        keep.append(stripe[-HALO_ROWS:].cpu().contiguous())
+        ops += [dist.P2POp(dist.isend, keep[-1], rank + 1, group), dist.P2POp(dist.irecv, recv_bot, rank + 1, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if top_n:
+        ext[:top_n] = recv_top.to(stripe.device)
+    if bot_n:
+        ext[top_n + (r1 - r0):] = recv_bot.to(stripe.device)
+    return ext, s0
+
+
 def forward_striped(stripe, height: int, world: int, rank: int,
                     compute_rows: Callable, group=None):
     """Row-striped forward pass of ONE plane: halo exchange + one kernel launch.
@@ -181,45 +215,48 @@ def forward_striped_launch(stripe, out, height: int, world: int, rank: int, laun
         return out
     if plan is None:
         if via_host:
-            ext, s0 = exchange_halo(stripe.cpu(), height, world, rank, group)
-            ext = ext.to(stripe.device)
+            ext, s0 = exchange_halo_via_host(stripe, height, world, rank, group)
         else:
             ext, s0 = exchange_halo(stripe, height, world, rank, group)
         launch_rows(ext, s0, out, r0, height, r0, r1)
         return out
     (i0, i1), top, bot = plan
-    # band inputs: [6 halo rows | first 12 own rows] and [last 12 own rows | 6 halo rows]
-    dev = "cpu" if via_host else stripe.device
-    width = stripe.shape[1]
-    src = stripe.cpu() if via_host else stripe
+    # band inputs on the device: [6 halo rows | first 12 own rows] and [last 12 own rows | 6 halo rows];
+    # only the 6-row halos travel (device to device over RCCL, or through host memory with via_host)
+    dev, width = stripe.device, stripe.shape[1]
+    xdev = "cpu" if via_host else dev
     ops, keep = [], []
-    top_buf = bot_buf = None
+    top_buf = bot_buf = recv_top = recv_bot = None
     if top:
         top_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
-        send = src[:HALO_ROWS].contiguous()
+        recv_top = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=xdev) if via_host else top_buf[:HALO_ROWS]
+        send = stripe[:HALO_ROWS].to(xdev).contiguous()
         keep.append(send)
-        ops += [dist.P2POp(dist.irecv, top_buf[:HALO_ROWS], rank - 1, group),
+        ops += [dist.P2POp(dist.irecv, recv_top, rank - 1, group),
                 dist.P2POp(dist.isend, send, rank - 1, group)]
     if bot:
         bot_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
-        send = src[-HALO_ROWS:].contiguous()
+        recv_bot = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=xdev) if via_host else bot_buf[2 * HALO_ROWS:]
+        send = stripe[-HALO_ROWS:].to(xdev).contiguous()
         keep.append(send)
         ops += [dist.P2POp(dist.isend, send, rank + 1, group),
-                dist.P2POp(dist.irecv, bot_buf[2 * HALO_ROWS:], rank + 1, group)]
+                dist.P2POp(dist.irecv, recv_bot, rank + 1, group)]
     reqs = dist.batch_isend_irecv(ops)
     launch_rows(stripe, r0, out, r0, height, i0, i1)          # overlaps the exchange
     if top:
-        top_buf[HALO_ROWS:] = src[:2 * HALO_ROWS]
+        top_buf[HALO_ROWS:] = stripe[:2 * HALO_ROWS]
     if bot:
-        bot_buf[:2 * HALO_ROWS] = src[-2 * HALO_ROWS:]
+        bot_buf[:2 * HALO_ROWS] = stripe[-2 * HALO_ROWS:]
     for req in reqs:
         req.wait()
     if top:
-        tb = top_buf.to(stripe.device) if via_host else top_buf
-        launch_rows(tb, r0 - HALO_ROWS, out, r0, height, top[0], top[1])
+        if via_host:
+            top_buf[:HALO_ROWS] = recv_top.to(dev)
+        launch_rows(top_buf, r0 - HALO_ROWS, out, r0, height, top[0], top[1])
     if bot:
-        bb = bot_buf.to(stripe.device) if via_host else bot_buf
-        launch_rows(bb, r1 - 2 * HALO_ROWS, out, r0, height, bot[0], bot[1])
+        if via_host:
+            bot_buf[2 * HALO_ROWS:] = recv_bot.to(dev)
+        launch_rows(bot_buf, r1 - 2 * HALO_ROWS, out, r0, height, bot[0], bot[1])
     return out
 
 

@@ -19,7 +19,11 @@ import srcnn_cpp_amd as S
 from srcnn_cpp_amd.synth import synth_batch
 
 pytestmark = pytest.mark.gpu
-PINS = json.loads((Path(__file__).resolve().parent / "golden" / "config_checksums.json").read_text())
+
+
+def pins(key):
+    return json.loads((Path(__file__).resolve().parent / "golden" / "config_checksums.json").read_text())[key]
+
 TOL_PRE_ABS = 5e-3
 
 
@@ -40,7 +44,7 @@ def shas(planes):
 
 def test_config2_batch_of_64_fused_and_unfused(gpu_ctx, weights_blob):
     import torch
-    pin = PINS["c2_3840x2160"]
+    pin = pins("c2_3840x2160")
     w, h, n = pin["width"], pin["height"], pin["frames"]
     assert (w, h, n) == (3840, 2160, 64)
     frames = synth_batch(w, h, n)
@@ -73,7 +77,7 @@ def test_config2_batch_of_64_fused_and_unfused(gpu_ctx, weights_blob):
 
 def test_config4_5760x3240_frame_stream(gpu_ctx, weights_blob):
     import torch
-    pin = PINS["c4_5760x3240"]
+    pin = pins("c4_5760x3240")
     w, h, n = pin["width"], pin["height"], pin["frames"]
     assert (w, h) == (5760, 3240) and n >= 8
     frames = synth_batch(w, h, n)

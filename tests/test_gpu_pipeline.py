@@ -78,8 +78,15 @@ def test_butterfly_example_on_gpu(gpu_ctx, weights_blob):
     out = gpu_ctx.process_bgr(src, 1.5)
     d = np.abs(out.astype(int) - ref.astype(int))
     assert out.shape == ref.shape and d.max() <= 2
-    assert (d.max(axis=2) == 0).mean() >= 0.995
+    assert (d.max(axis=2) == 0).mean() >= 0.9995          # MFMA mode: a handful of pixels on a truncation boundary
     assert np.array_equal(out, oracle.process_bgr(src, 1.5, weights_blob, y_path=oracle.gpuorder_forward_y))
+    # SRCNN_MODE_EXACT on the GPU reproduces the reference's published picture bit for bit, all 995,328 bytes
+    gpu_ctx.set_mode(S.MODE_EXACT)
+    try:
+        exact = gpu_ctx.process_bgr(src, 1.5)
+    finally:
+        gpu_ctx.set_mode(S.MODE_MFMA)
+    assert np.array_equal(exact, ref)
 
 
 def test_pipeline_device_entry_point(gpu_ctx, weights_blob):
