@@ -32,8 +32,11 @@ __all__ = [
     "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
 
+import os
+
 _PKG = Path(__file__).resolve().parent
-_LIB_PATH = _PKG / "libsrcnn_amd.so"
+# SRCNN_LIB: an alternative build of the library for same-box A/B timing (tools/ab_build.sh); never set in production
+_LIB_PATH = Path(os.environ["SRCNN_LIB"]) if os.environ.get("SRCNN_LIB") else _PKG / "libsrcnn_amd.so"
 _WEIGHTS_PATH = _PKG / "data" / "srcnn915_weights.f32"
 
 MODE_MFMA = 0

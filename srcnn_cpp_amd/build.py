@@ -13,11 +13,15 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
-LIB = PKG / "libsrcnn_amd.so"
-OBJ = PKG.parent / "build"
+# SRCNN_BUILD_VARIANT=name [+ SRCNN_BUILD_DEFINES="-DX -DY"]: an alternative library libsrcnn_amd_<name>.so with its own
+# object directory, for same-box A/B timing (load it with SRCNN_LIB=...); the default build is the product
+VARIANT = os.environ.get("SRCNN_BUILD_VARIANT", "")
+LIB = PKG / (f"libsrcnn_amd_{VARIANT}.so" if VARIANT else "libsrcnn_amd.so")
+OBJ = PKG.parent / ("build" + (f"_{VARIANT}" if VARIANT else ""))
 
 ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("SRCNN_BUILD_DEFINES", "").split()
 if os.environ.get("SRCNN_ABLATION_BUILD"):      # timing-only ablation kernels (profiles/rNN/ablation.txt); never shipped
     COMMON.append("-DSRCNN_ABLATION_BUILD")
 # (source, extra flags).  srcnn_exact.hip reproduces the reference's

@@ -401,10 +401,161 @@ struct ItemPlan {
     int n_seams() const { return (int)seams.size() / 2; }
 };
 
+// Balanced plan for two workgroups per CU with seams (the float32 fused kernel on a plane launched alone).
+//
+// Measured (tools/diag_light.py, profiles/r02/diag_light_*.txt): with two workgroups on a CU the first-dispatched
+// one (wave slot 0 wins the age-based MFMA arbitration) takes kPairFast us per row, the one that joins it kPairSlow;
+// a workgroup left alone on its CU takes kAlone -- less per row than either, but more than half of both together,
+// so a CU is fastest when its two items end together, and the launch ends with the slowest CU.  The round-1 planner
+// cut every strip into k or k+1 items of two heights and paired tall with short: CUs carried 247..255 rows and
+// the median CU idled for the last 1.5-3.4 % of the launch.
+//
+// Here: same item counts per strip (every strip is tiled exactly by ITS items, whatever their order), same pairing
+// to start from, then a local search moves single rows between two items of the same strip while that lowers the
+// estimated finish time of the slower of the two CUs involved -- until the slowest CU cannot be improved.
+// `cu_speed` (optional, one factor per CU) scales the estimate per CU.  It is not used in production: feeding back the
+// per-XCD finish times of earlier launches was tried and made things worse -- which XCD runs 1-2 % slow changes from
+// launch to launch (profiles/r02/ablation.txt).  Placement only affects speed: any plan computes the same plane.
+constexpr double kPairFast = 6.85, kPairSlow = 8.35, kAlone = 4.3, kStartFast = 3.0, kStartSlow = 7.2;   // us
+
+double cu_finish_estimate(int fast_rows, int slow_rows, double speed)
+{
+    const double tf = kStartFast + fast_rows * kPairFast, ts = kStartSlow + slow_rows * kPairSlow;
+    double t;
+    if (tf <= ts) t = tf + std::max(0.0, slow_rows - (tf - kStartSlow) / kPairSlow) * kAlone;     // the slow one is left alone
+    else t = ts + std::max(0.0, fast_rows - (ts - kStartFast) / kPairFast) * kAlone;
+    return t / speed;
+}
+
+ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, const double *cu_speed = nullptr)
+{
+    const ItemPlan none;
+    constexpr int kMinRows = 10;
+    const int hs = row_end - row_begin;
+    const int slots = 2 * n_cu;
+    if (n_cu <= 0 || n_strips <= 0 || n_strips > n_cu || hs <= 0 || slots / n_strips < 2 || hs / (slots / n_strips + 1) < kMinRows + 2)
+        return none;
+    // items per strip and how many of them go to first-dispatched blocks (as many fast as slow items overall)
+    const int kbase = slots / n_strips, kextra = slots % n_strips;
+    std::vector<int> k((size_t)n_strips), a((size_t)n_strips);
+    int fast_total = 0;
+    for (int s = 0; s < n_strips; ++s) {
+        k[(size_t)s] = kbase + (s < kextra ? 1 : 0);
+        a[(size_t)s] = k[(size_t)s] / 2;
+        fast_total += a[(size_t)s];
+    }
+    for (int pass = 0; pass < 2 && fast_total < n_cu; ++pass)
+        for (int s = 0; s < n_strips && fast_total < n_cu; ++s)
+            if ((pass == 1 || k[(size_t)s] % 2 == 1) && a[(size_t)s] < k[(size_t)s] - 1) { ++a[(size_t)s]; ++fast_total; }
+    if (fast_total != n_cu) return none;
+    struct Item { int strip, rows, cu; bool fast; };
+    std::vector<Item> items;
+    const double d = std::min(std::max(skew_pct, 0), 60) / 100.0;
+    for (int s = 0; s < n_strips; ++s) {
+        const int na = a[(size_t)s], nb = k[(size_t)s] - na;
+        const double u = hs / (na * (1.0 + d) + nb * (1.0 - d));
+        double acc = 0.0;
+        int used = 0;
+        for (int j = 0; j < k[(size_t)s]; ++j) {               // alternate tall / short down the strip
+            const bool fast = (j % 2 == 0) ? (j / 2 < na) : !((j / 2) < nb);
+            acc += fast ? (1.0 + d) * u : (1.0 - d) * u;
+            const int upto = (j == k[(size_t)s] - 1) ? hs : (int)std::lround(acc);
+            items.push_back({s, upto - used, -1, fast});
+            used = upto;
+        }
+    }
+    // the alternation above may not hand out exactly na fast items per strip when na != nb: recount and fix the flags
+    for (int s = 0; s < n_strips; ++s) {
+        int have = 0;
+        for (auto &it : items) if (it.strip == s && it.fast) ++have;
+        for (auto &it : items) if (it.strip == s && have > a[(size_t)s] && it.fast) { it.fast = false; --have; }
+        for (auto &it : items) if (it.strip == s && have < a[(size_t)s] && !it.fast) { it.fast = true; ++have; }
+    }
+    // pair the tallest fast item with the shortest slow one
+    std::vector<int> fi, si;
+    for (int i = 0; i < (int)items.size(); ++i) (items[(size_t)i].fast ? fi : si).push_back(i);
+    if ((int)fi.size() != n_cu || (int)si.size() != n_cu) return none;
+    std::stable_sort(fi.begin(), fi.end(), [&](int x, int y) { return items[(size_t)x].rows > items[(size_t)y].rows; });
+    std::stable_sort(si.begin(), si.end(), [&](int x, int y) { return items[(size_t)x].rows < items[(size_t)y].rows; });
+    for (int c = 0; c < n_cu; ++c) items[(size_t)fi[(size_t)c]].cu = items[(size_t)si[(size_t)c]].cu = c;
+    auto speed = [&](int c) { return cu_speed && cu_speed[c] > 0.5 && cu_speed[c] < 2.0 ? cu_speed[c] : 1.0; };
+    auto finish = [&](int c) { return cu_finish_estimate(items[(size_t)fi[(size_t)c]].rows, items[(size_t)si[(size_t)c]].rows, speed(c)); };
+    // local search: take one row from an item of the slowest improvable CU, give it to the item of the same strip
+    // whose CU stays fastest; stop when no such move lowers the pair's maximum
+    std::vector<std::vector<int>> in_strip((size_t)n_strips);
+    for (int i = 0; i < (int)items.size(); ++i) in_strip[(size_t)items[(size_t)i].strip].push_back(i);
+    std::vector<double> fin((size_t)n_cu);
+    for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
+    std::vector<int> by_time((size_t)n_cu);
+    for (int iter = 0; iter < 40 * n_cu; ++iter) {
+        for (int c = 0; c < n_cu; ++c) by_time[(size_t)c] = c;
+        std::sort(by_time.begin(), by_time.end(), [&](int x, int y) { return fin[(size_t)x] > fin[(size_t)y]; });
+        bool moved = false;
+        for (int rank = 0; rank < n_cu && !moved; ++rank) {
+            const int c = by_time[(size_t)rank];
+            double best_gain = 1e-6;
+            int best_from = -1, best_to = -1;
+            for (int from : {fi[(size_t)c], si[(size_t)c]}) {
+                if (items[(size_t)from].rows <= kMinRows) continue;
+                items[(size_t)from].rows -= 1;
+                const double mine = finish(c);
+                for (int to : in_strip[(size_t)items[(size_t)from].strip]) {
+                    const int c2 = items[(size_t)to].cu;
+                    if (c2 == c) continue;
+                    items[(size_t)to].rows += 1;
+                    const double theirs = finish(c2);
+                    const double gain = fin[(size_t)c] - std::max(mine, theirs);
+                    if (theirs < fin[(size_t)c] && gain > best_gain) { best_gain = gain; best_from = from; best_to = to; }
+                    items[(size_t)to].rows -= 1;
+                }
+                items[(size_t)from].rows += 1;
+            }
+            if (best_from >= 0) {
+                items[(size_t)best_from].rows -= 1;
+                items[(size_t)best_to].rows += 1;
+                fin[(size_t)c] = finish(c);
+                fin[(size_t)items[(size_t)best_to].cu] = finish(items[(size_t)best_to].cu);
+                moved = true;
+            }
+        }
+        if (!moved) break;
+    }
+    // positions: the items of a strip in creation order; seams between neighbours
+    ItemPlan plan;
+    std::vector<int> y0(items.size()), up(items.size(), -1), dn(items.size(), -1);
+    for (int s = 0; s < n_strips; ++s) {
+        int y = row_begin, prev = -1;
+        for (int i : in_strip[(size_t)s]) {
+            if (items[(size_t)i].rows < 2 * SEAM_ROWS) return none;
+            y0[(size_t)i] = y;
+            y += items[(size_t)i].rows;
+            if (prev >= 0) {
+                const int id = plan.n_seams();
+                plan.seams.insert(plan.seams.end(), {s, y0[(size_t)i]});
+                dn[(size_t)prev] = id;
+                up[(size_t)i] = id;
+            }
+            prev = i;
+        }
+        if (y != row_end) return none;
+    }
+    auto emit = [&](int i) {
+        plan.items.insert(plan.items.end(), {items[(size_t)i].strip, y0[(size_t)i], y0[(size_t)i] + items[(size_t)i].rows, up[(size_t)i], dn[(size_t)i]});
+    };
+    for (int c = 0; c < n_cu; ++c) emit(fi[(size_t)c]);
+    for (int c = 0; c < n_cu; ++c) emit(si[(size_t)c]);
+    return plan;
+}
+
 ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
                     bool want_seams = false)
 {
     const ItemPlan none;
+    static const char *env_plan = std::getenv("SRCNN_DEBUG_PLAN");      // experiment knob: 1 = the round-1 planner
+    if (wgs_per_cu == 2 && want_seams && skew_pct > 0 && !(env_plan && std::atoi(env_plan) == 1)) {
+        const ItemPlan balanced = plan_items_balanced(n_cu, n_strips, row_begin, row_end, skew_pct);
+        if (balanced.count() > 0) return balanced;
+    }
     const int rows = row_end - row_begin;
     int slots = wgs_per_cu * n_cu;
     // shortest useful item: with halo rows to recompute (4 per item) short items do not pay; with seams an item
@@ -483,6 +634,12 @@ int skew_percent()
 // Device copy of plan_items() for this geometry, from the context's table cache.  *n_items = 0: use the
 // regular grid.  A table is written once, before its first use, into memory no earlier launch reads
 // (a fresh slot, or an evicted one after its last reader has finished), and never modified afterwards.
+bool balanced_plan_wanted(int wgs_per_cu, bool want_seams, int skew_pct)
+{
+    static const char *env_plan = std::getenv("SRCNN_DEBUG_PLAN");      // experiment knob: 1 = the round-1 planner
+    return wgs_per_cu == 2 && want_seams && skew_pct > 0 && !(env_plan && std::atoi(env_plan) == 1);
+}
+
 int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
                 const srcnn_ctx::ItemTable **table)
 {
@@ -497,10 +654,16 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
         }
         if (t.stamp < victim->stamp) victim = &t;
     }
-    const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
+    ItemPlan plan;
+    bool balanced = false;
+    if (balanced_plan_wanted(wgs_per_cu, want_seams, key[3])) {
+        plan = plan_items_balanced(c->n_cu, n_strips, row_begin, row_end, key[3]);
+        balanced = plan.count() > 0;
+    }
+    if (!balanced) plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
+    if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());              // evicting: its readers must be done
     if (plan.count() > 0) {
         int rc;
-        if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());          // evicting: its readers must be done
         if ((rc = reserve(c, victim->dev, plan.items.size() * sizeof(int)))) return rc;
         HIP_TRY(c, hipMemcpy(victim->dev.p, plan.items.data(), plan.items.size() * sizeof(int), hipMemcpyHostToDevice));
         if (plan.n_seams() > 0) {
@@ -642,6 +805,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
+    if (p.tune & 32) return SRCNN_OK;          // timing experiment: strip kernel only (wrong pixels next to the seams)
     if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams, static_cast<const int *>(table->dev_seams.p), c->stream));
     if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     return SRCNN_OK;

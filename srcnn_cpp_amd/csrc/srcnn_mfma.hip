@@ -134,12 +134,17 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
     }
 }
 
+// DIAG: 1 = cycle stamps around every phase of every row (SRCNN_DEBUG_TUNE & 2; perturbs the timing, runs without
+// seams), 2 = four wall-clock stamps per wave -- entry, loop start, loop end, exit -- on the production launch
+// (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output.
 // ABL != 0: timing-only ablation builds (WRONG results by construction; SRCNN_DEBUG_TUNE bits 8..12 select one,
 // profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
 // instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS.
-template <int MODE, bool PRE, bool DIAG = false, int ABL = 0>
+template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
 {
+    unsigned long long lt[4] = {0, 0, 0, 0};
+    if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *ylds = reinterpret_cast<float *>(smem);   // [2*YR][YP]   (MODE_FUSED, MODE_L12)
     float *fbuf = ylds + 2 * YR * YP;                // [2][3][6][FW]  (MODE_FUSED, MODE_L3)
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             seam_up = it[3];
             seam_dn = it[4];
         }
+        if (ys >= ye) return;      // placeholder (no rows)
     } else {
         if (!(p.tune & 8)) {
             const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -266,10 +272,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
         return t;
     };
     unsigned long long dg_t0 = 0, dg_r0 = 0, dg_l1 = 0, dg_l23 = 0, dg_bar = 0, dg_top = 0;
-    if constexpr (DIAG) {
+    if constexpr (DIAG == 1) {
         dg_t0 = stamp();
         dg_r0 = __builtin_amdgcn_s_memrealtime();
     }
+    if constexpr (DIAG == 2) lt[1] = __builtin_amdgcn_s_memrealtime();
 
     const int xi = 32 * wave + j;      // this lane's feature column in the strip
     const int gx = gx0 + xi;           // ... and in the image
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     if constexpr (MODE == MODE_L3) load_planes(f_lo);
     for (int f = f_lo; f <= f_end; ++f) {
         unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
-        if constexpr (DIAG) dg_a = stamp();
+        if constexpr (DIAG == 1) dg_a = stamp();
         const bool do_a = f < f_hi;
         const int g = f - 1;
         const bool hp = (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 whenever do_a
@@ -447,10 +454,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if constexpr (DIAG) dg_b = stamp();
+            if constexpr (DIAG == 1) dg_b = stamp();
             if (hp) layer1(std::true_type{});
             else layer1(std::false_type{});
-            if constexpr (DIAG) dg_c = stamp();
+            if constexpr (DIAG == 1) dg_c = stamp();
             // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
             // dependent MFMAs breaks their back-to-back issue (~64 -> ~81 cycles per MFMA,
             // tools/mfma_probe.hip), 32 of them up front cost ~140 cycles once.
@@ -508,9 +515,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             else vertical(f, t);
         }
 
-        if constexpr (DIAG) dg_d = stamp();
+        if constexpr (DIAG == 1) dg_d = stamp();
         if constexpr (!(ABL & 1)) lds_barrier();
-        if constexpr (DIAG) {
+        if constexpr (DIAG == 1) {
             const unsigned long long e = stamp();
             dg_top += dg_b - dg_a;
             dg_l1 += dg_c - dg_b;
@@ -518,6 +525,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
             dg_bar += e - dg_d;
         }
     }
+    if constexpr (DIAG == 2) lt[2] = __builtin_amdgcn_s_memrealtime();
     if (bot_open) {
         // hand the vertical chains (taps of this item's last rows) to the seam below
         float *o = p.seam + (long)seam_dn * SEAM_FLOATS * NTHREADS + tid;
@@ -526,7 +534,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
 #pragma unroll
             for (int s = 0; s < 3; ++s) o[(k * 3 + s) * NTHREADS] = R[k][s];
     }
-    if constexpr (DIAG) {
+    if constexpr (DIAG == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lt[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) + ((long)blockIdx.x * NWAVES + wave) * 8;
+            o[0] = lt[0];
+            o[1] = lt[1];
+            o[2] = lt[2];
+            o[3] = lt[3];
+            o[4] = (unsigned long long)(f_hi - f_lo);
+            o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
+            o[6] = (unsigned long long)strip | ((unsigned long long)ys << 32);
+        }
+    }
+    if constexpr (DIAG == 1) {
         const unsigned long long t1 = stamp();
         const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
@@ -665,9 +688,10 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
     const bool pre = p.pre != nullptr;
     switch (mode) {
     case MODE_FUSED:
-        if (p.tune & 2) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, true>), grid, block, lds, stream, p);
+        if (p.tune & 2) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 1>), grid, block, lds, stream, p);
+        else if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
 #ifdef SRCNN_ABLATION_BUILD
-#define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, false, n>), grid, block, lds, stream, p); break;
+#define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, n>), grid, block, lds, stream, p); break;
         else if ((p.tune >> 8) & 31) {
             switch ((p.tune >> 8) & 31) {
                 ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31)

@@ -66,7 +66,7 @@ int main(int argc, char **argv)
                                 std::vector<long> covered((size_t)n_strips, 0);
                                 for (int i = 0; i < n; ++i) {
                                     const int *it = &items[(size_t)srcnn::ITEM_INTS * i];
-                                    CHECK(it[0] >= 0 && it[0] < n_strips && it[1] >= row_begin && it[2] <= row_begin + rows && it[1] < it[2]);
+                                    CHECK(it[0] >= 0 && it[0] < n_strips && it[1] >= row_begin && it[2] <= row_begin + rows && it[1] <= it[2]);
                                     CHECK(it[3] >= -1 && it[3] < n_seams && it[4] >= -1 && it[4] < n_seams);
                                     covered[(size_t)it[0]] += it[2] - it[1];
                                 }
