@@ -187,6 +187,11 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true",
                     help="stripe workload: wait for the halo before the one launch (default: interior rows first, "
                          "the two 6-row edge bands after the exchange)")
+    ap.add_argument("--prewarm-ms", type=float, default=400.0,
+                    help="untimed device wake-up BEFORE the W warm-up steps: the same step, repeated for this long.  An idle "
+                         "MI355X needs ~20 launches (20-30 ms) of load to reach its steady clocks -- the first steps after "
+                         "idle run 4-10 %% slower (profiles/r02/clock_ramp.txt) -- and the contract's W = 5 steps are 5 ms.  "
+                         "0 disables it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -304,6 +309,20 @@ def worker(args):
         if dist is not None:
             dist.barrier()
 
+    # untimed: bring the device from idle to its steady clocks, then the W warm-up steps of the contract
+    prewarm_steps = 0
+    if args.prewarm_ms > 0 and stripe and world > 1:
+        for _ in range(64):                 # ranks exchange halos every step: the same COUNT on every rank, not a duration
+            step()
+        torch.cuda.synchronize()
+        prewarm_steps = 64
+    elif args.prewarm_ms > 0:
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+            prewarm_steps += 8
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -402,6 +421,8 @@ def worker(args):
                          "traffic_source": pmc_ref["source"] if pmc_ref else None,
                          "kernel_ms": round(kern_ms, 4), "flop_per_pixel": S.FLOP_PER_PIXEL},
             "per_rank_ms_per_step": [round(v, 4) for v in per_rank_ms],
+            "prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps,
+                        "why": "untimed clock ramp before the W warm-up steps; an idle GPU runs its first ~20 launches slower"},
         }
         if pmc_ref:
             out["pmc_reference"] = pmc_ref

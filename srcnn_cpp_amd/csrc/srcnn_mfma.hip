@@ -61,6 +61,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // Row barrier.  The waves of a workgroup only exchange data through LDS, so the barrier has to
@@ -143,6 +144,7 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
 {
+    if (p.tune & 64) return;        // timing experiment: what an empty launch of this grid costs
     unsigned long long lt[4] = {0, 0, 0, 0};
     if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
