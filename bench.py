@@ -268,7 +268,8 @@ def worker(args):
         frames = synth_batch(W, H, F, first_frame=rank * F)
     d_in = torch.from_numpy(frames).cuda()
     d_out = torch.zeros_like(d_in)
-    d_work = torch.empty((F, 32, H, W), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
+    plpad = int(os.environ.get("SRCNN_DEBUG_PLPAD", "0"))           # experiment knob: see srcnn_forward_y_unfused_dev
+    d_work = torch.empty((F * 32 * (H * W + plpad),), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
 
     host_out = np.empty_like(frames[0])
     host_frames = np.empty_like(frames) if args.path == "host" and F > 1 else None

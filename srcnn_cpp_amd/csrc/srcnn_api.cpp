@@ -683,6 +683,25 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
 // The split-f16 kernel is software-pipelined inside a wave and runs one workgroup per CU (srcnn_split16.hip).
 int split16_wgs_per_cu(bool split16, int /*tune*/) { return split16 ? 1 : 2; }
 
+// Seam scratch of the stream the context launches on (one buffer set per stream: srcnn_ctx::SeamScratch).
+int seam_scratch_for_stream(srcnn_ctx *c, srcnn_ctx::SeamScratch **out)
+{
+    srcnn_ctx::SeamScratch *sc = nullptr;
+    for (auto &e : c->seam_scratch)
+        if (e.used && e.stream == c->stream) sc = &e;
+    for (auto &e : c->seam_scratch)
+        if (!sc && !e.used) sc = &e;
+    if (!sc) {                  // more streams than slots: wait for everything, start over with slot 0
+        HIP_TRY(c, hipDeviceSynchronize());
+        for (auto &e : c->seam_scratch) e.used = false;
+        sc = &c->seam_scratch[0];
+    }
+    sc->used = true;
+    sc->stream = c->stream;
+    *out = sc;
+    return SRCNN_OK;
+}
+
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
@@ -710,9 +729,31 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     p.strips_total = pl.n_strips;
     int grid_items = 0;
     const srcnn_ctx::ItemTable *table = nullptr;
+    // Convolution55 alone (MODE_L3) reads 128 B per pixel and is bound by HBM: strips of exactly FW = 128 columns
+    // (column seams instead of 2 halo columns each side), so that the four waves of a workgroup read four whole
+    // 128-byte lines per plane and row -- with 124-column strips every strip start falls inside a line and a fifth
+    // line is fetched: 1.32 x the algorithmic bytes by FETCH_SIZE (profiles/r02) -- and four workgroups per CU
+    // (<= 128 VGPRs, 18 KB of LDS) to keep 64 KB of loads in flight per CU.  SRCNN_DEBUG_L3=0: the round-1 launch.
+    static const char *env_l3 = std::getenv("SRCNN_DEBUG_L3");
+    const int ns_l3 = (p.width + FW - 1) / FW;
+    const bool l3_aligned = mode == MODE_L3 && !(env_l3 && std::atoi(env_l3) == 0) &&
+                            (p.width - (ns_l3 - 1) * FW >= 4 || ns_l3 == 1);
+    if (l3_aligned) {
+        pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo, 4, 0);
+        p.seg_rows = pl.seg_rows;
+        p.n_strips = pl.n_strips;
+        p.n_segs = pl.n_segs;
+        p.strips_total = pl.n_strips;
+        srcnn_ctx::SeamScratch *sc = nullptr;
+        int rc;
+        if ((rc = seam_scratch_for_stream(c, &sc))) return rc;
+        const size_t n = (size_t)n_frames * p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
+        if ((rc = reserve(c, sc->cbuf, n))) return rc;
+        p.cseam = static_cast<float *>(sc->cbuf.p);
+    }
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
-    if (mode != MODE_L12 && n_frames == 1) {
+    if (mode != MODE_L12 && n_frames == 1 && !l3_aligned) {
         // float32 fused kernel only: seams instead of halo rows between the items of a strip, and column seams
         // instead of halo columns between strips (srcnn_kernels.h).  SRCNN_DEBUG_SEAMS: 0 = neither, 1 = rows only.
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
@@ -1222,7 +1263,8 @@ int srcnn_forward_y_unfused_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_s
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || !d_work ||
         n_frames <= 0)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_unfused_dev: bad arguments");
-    const long pitch = (long)width * height;
+    static const char *env_plpad = std::getenv("SRCNN_DEBUG_PLPAD");     // experiment: floats added to the plane pitch
+    const long pitch = (long)width * height + (env_plpad ? std::atol(env_plpad) : 0);
     if (c->mode == SRCNN_MODE_EXACT) {
         HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, (long)src_frame_pitch, d_work, width, pitch,
                                           32 * pitch, width, height, n_frames,
@@ -1417,7 +1459,6 @@ int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t
 {
     BIND(c);
     int rc = SRCNN_OK;
-    (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) ||
         (preclamp && preclamp_stride < (size_t)width))
@@ -1426,18 +1467,71 @@ int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t
     if ((rc = reserve(c, c->in_u8, n))) return rc;
     if ((rc = reserve(c, c->out_u8, n))) return rc;
     if (preclamp && (rc = reserve(c, c->pre_f32, n * 4))) return rc;
-    HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src, src_stride, width, height, hipMemcpyHostToDevice,
-                                c->stream));
-    rc = srcnn_forward_y_dev(c, static_cast<uint8_t *>(c->in_u8.p), width, n,
-                             static_cast<uint8_t *>(c->out_u8.p), width, n, width, height, 1,
-                             preclamp ? static_cast<float *>(c->pre_f32.p) : nullptr);
+    uint8_t *d_in = static_cast<uint8_t *>(c->in_u8.p), *d_out = static_cast<uint8_t *>(c->out_u8.p);
+    float *d_pre = preclamp ? static_cast<float *>(c->pre_f32.p) : nullptr;
+    // A large plane goes through in row bands: band i's rows are uploaded while band i-1 computes, and band i-1's
+    // result comes back while band i computes, so only the first upload and the last download are exposed
+    // (copies from / to pageable memory block this thread, not the other streams).  Any partition of the rows
+    // computes the same plane (srcnn_forward_y_rows_dev).  EXACT mode and small planes: one upload, one launch.
+    static const char *env_bands = std::getenv("SRCNN_DEBUG_BANDS");
+    // bands of >= 1024 rows: shorter ones lose more in their launches than the overlap wins (measured: 3840x2160 1.35 ms
+    // in one piece, 1.27 in two bands, 1.28 in four, 1.40 in eight; 7680x4320 5.20 -> 4.44 in four)
+    int n_bands = env_bands ? std::atoi(env_bands) : ((long)width * height >= (4L << 20) ? std::min(8, height / 1024) : 1);
+    if (c->mode == SRCNN_MODE_EXACT || preclamp || n_bands < 1) n_bands = 1;
+    n_bands = std::min(n_bands, std::max(1, height / 64));
+    if (n_bands == 1) {
+        HIP_TRY(c, hipMemcpy2DAsync(d_in, width, src, src_stride, width, height, hipMemcpyHostToDevice, c->stream));
+        rc = srcnn_forward_y_dev(c, d_in, width, n, d_out, width, n, width, height, 1, d_pre);
+        if (rc) return rc;
+        HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, d_out, width, width, height, hipMemcpyDeviceToHost, c->stream));
+        if (preclamp)
+            HIP_TRY(c, hipMemcpy2DAsync(preclamp, preclamp_stride * 4, d_pre, (size_t)width * 4, (size_t)width * 4, height,
+                                        hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return SRCNN_OK;
+    }
+    for (int k = 0; k < 2; ++k)
+        if (!c->lane_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+    hipStream_t s_up = c->lane_stream[0], s_down = c->lane_stream[1];
+    std::vector<hipEvent_t> up((size_t)n_bands, nullptr), done((size_t)n_bands, nullptr);
+    auto cleanup = [&] {
+        for (auto e : up) if (e) (void)hipEventDestroy(e);
+        for (auto e : done) if (e) (void)hipEventDestroy(e);
+    };
+    hipError_t e = hipStreamSynchronize(c->stream);            // earlier work on the context's buffers
+    int uploaded = 0;
+    for (int i = 0; i < n_bands && e == hipSuccess && rc == SRCNN_OK; ++i) {
+        int r0, r1;
+        srcnn_stripe_rows(height, n_bands, i, &r0, &r1);
+        const int need = std::min(height, r1 + 6);             // the band reads 6 rows beyond its own
+        if (need > uploaded) {
+            e = hipMemcpy2DAsync(d_in + (size_t)uploaded * width, width, src + (size_t)uploaded * src_stride, src_stride,
+                                 width, need - uploaded, hipMemcpyHostToDevice, s_up);
+            uploaded = need;
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&up[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(up[(size_t)i], s_up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, up[(size_t)i], 0);
+        if (e != hipSuccess) break;
+        rc = srcnn_forward_y_rows_dev(c, d_in, width, 0, d_out, width, 0, width, height, r0, r1);
+        if (rc) break;
+        e = hipEventCreateWithFlags(&done[(size_t)i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(done[(size_t)i], c->stream);
+    }
+    for (int i = 0; i < n_bands && e == hipSuccess && rc == SRCNN_OK; ++i) {
+        int r0, r1;
+        srcnn_stripe_rows(height, n_bands, i, &r0, &r1);
+        e = hipStreamWaitEvent(s_down, done[(size_t)i], 0);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(dst + (size_t)r0 * dst_stride, dst_stride, d_out + (size_t)r0 * width, width, width, r1 - r0,
+                                 hipMemcpyDeviceToHost, s_down);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+    (void)hipStreamSynchronize(s_up);
+    (void)hipStreamSynchronize(c->stream);
+    cleanup();
     if (rc) return rc;
-    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->out_u8.p, width, width, height, hipMemcpyDeviceToHost,
-                                c->stream));
-    if (preclamp)
-        HIP_TRY(c, hipMemcpy2DAsync(preclamp, preclamp_stride * 4, c->pre_f32.p, (size_t)width * 4,
-                                    (size_t)width * 4, height, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (e != hipSuccess) return fail(c, SRCNN_ERR_HIP, "forward_y: %s", hipGetErrorString(e));
     return SRCNN_OK;
 }
 

@@ -142,14 +142,14 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 // profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
 // instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS.
 template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
-__global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripParams p)
+__global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
     if (p.tune & 64) return;        // timing experiment: what an empty launch of this grid costs
     unsigned long long lt[4] = {0, 0, 0, 0};
     if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *ylds = reinterpret_cast<float *>(smem);   // [2*YR][YP]   (MODE_FUSED, MODE_L12)
-    float *fbuf = ylds + 2 * YR * YP;                // [2][3][6][FW]  (MODE_FUSED, MODE_L3)
+    float *fbuf = (MODE == MODE_L3) ? ylds : ylds + 2 * YR * YP;      // [2][3][6][FW]  (MODE_FUSED, MODE_L3)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_kernel(const StripPar
     }
 
     // column seams (srcnn_kernels.h): the strip outputs all FW columns, its four edge pixels are finished elsewhere
-    const bool cs = (MODE == MODE_FUSED) && p.cseam != nullptr;
+    const bool cs = (MODE != MODE_L12) && p.cseam != nullptr;
     const CseamLane cl = cseam_lane((cs && threadIdx.x < 15) ? (int)threadIdx.x : 15);
     const int halo_c = cs ? 0 : HALO;
     const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
@@ -676,9 +676,10 @@ hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, h
     return hipGetLastError();
 }
 
-size_t strip_lds_bytes(int /*mode*/)
+size_t strip_lds_bytes(int mode)
 {
-    return sizeof(float) * (2 * YR * YP + 2 * 3 * 6 * FW);
+    // Y ring (layers 1-2) + F tiles (layer 3); Convolution55 alone needs only the tiles
+    return sizeof(float) * ((mode == MODE_L3 ? 0 : 2 * YR * YP) + 2 * 3 * 6 * FW);
 }
 
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)

@@ -308,6 +308,13 @@ def test_full_size_4k_frame(gpu_ctx, weights_blob):
     y = synth_luma(w, h)
     pre = np.empty((h, w), np.float32)
     out = gpu_ctx.forward_y(y, preclamp=pre)
+    # without the optional pre-clamp plane the host entry point pipelines the plane through in four row bands
+    # (uploads, launches and downloads of neighbouring bands overlap): same bytes
+    assert np.array_equal(gpu_ctx.forward_y(y), out)
+    padded = np.zeros((h, w + 64), np.uint8)
+    padded[:, :w] = y
+    dst = np.zeros((h, w + 32), np.uint8)
+    assert np.array_equal(gpu_ctx.forward_y(padded[:, :w], dst=dst[:, :w]), out)      # padded row strides, both sides
     # size-independent property: 13x13 locality -- crops reproduce the frame
     for (r0, c0) in [(0, 0), (1000, 2000), (h - 80, w - 200), (0, w - 150), (h - 64, 0)]:
         r1, c1 = min(h, r0 + 80), min(w, c0 + 200)
