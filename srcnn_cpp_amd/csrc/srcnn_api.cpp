@@ -753,7 +753,12 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     // One plane that fits the GPU in a single round: size the work items by the speed of the wave
     // slot they will land in and use every slot (build_items).
-    if (mode != MODE_L12 && n_frames == 1 && !l3_aligned) {
+    const bool fused32 = mode == MODE_FUSED && !split16;
+    // A small batch repeats the plane's item plan frame after frame in one launch (no halo rows, and the next frame's
+    // blocks fill the CUs the last items of a frame leave idle): 8 x 3840x2160 0.857 against 0.839 on the regular
+    // grid; from kItemBatchMax frames on the regular grid's tall segments are as good (64 frames: 0.863 vs 0.865).
+    constexpr int kItemBatchMax = 32;
+    if (mode != MODE_L12 && (n_frames == 1 || (fused32 && n_frames < kItemBatchMax && !(p.tune & (2 | 128)))) && !l3_aligned) {   // tune 128: regular grid (A/B)
         // float32 fused kernel only: seams instead of halo rows between the items of a strip, and column seams
         // instead of halo columns between strips (srcnn_kernels.h).  SRCNN_DEBUG_SEAMS: 0 = neither, 1 = rows only.
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
@@ -793,22 +798,24 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
                 sc->used = true;
                 sc->stream = c->stream;
                 if (table->n_seams > 0) {
-                    if ((rc = reserve(c, sc->buf, (size_t)table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
+                    if ((rc = reserve(c, sc->buf, (size_t)n_frames * table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
                     p.seam = static_cast<float *>(sc->buf.p);
                 }
                 if (col_seams) {
-                    const size_t n = (size_t)p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
+                    const size_t n = (size_t)n_frames * p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
                     if ((rc = reserve(c, sc->cbuf, n))) return rc;
                     p.cseam = static_cast<float *>(sc->cbuf.p);
                 }
             }
             p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
             p.n_segs = grid_items;
+            p.items_per_frame = grid_items;
+            p.seams_per_frame = std::max(1, table->n_seams);
         }
     }
     // Batches (regular grid): column seams only -- the planner already makes the segments tall, and a row seam
     // costs 74 KB of scratch.
-    if (mode == MODE_FUSED && !split16 && n_frames > 1 && !(p.tune & 2)) {
+    if (fused32 && n_frames > 1 && !(p.tune & 2) && grid_items == 0) {
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
         const int ns_cs = (p.width + FW - 1) / FW;
         if ((!env_seams || (std::atoi(env_seams) & 2)) && (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1)) {
@@ -847,7 +854,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     if (p.tune & 32) return SRCNN_OK;          // timing experiment: strip kernel only (wrong pixels next to the seams)
-    if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams, static_cast<const int *>(table->dev_seams.p), c->stream));
+    if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p), c->stream));
     if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     return SRCNN_OK;
 }
@@ -1175,15 +1182,15 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
-    if (n_frames == 1) {                // single-round launch with explicit work items (plan_items)
+    if (n_frames == 1 || (c->mode == SRCNN_MODE_MFMA && n_frames < 32)) {   // explicit work items (plan_items), repeated per frame of a small batch
         const std::vector<int> items =
             plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), items_per_cu,
                        c->mode == SRCNN_MODE_MFMA && (seam_knob & 1)).items;
         if (!items.empty()) {
-            out[0] = (int)items.size() / ITEM_INTS;
+            out[0] = (int)items.size() / ITEM_INTS * n_frames;
             out[1] = 0;
             for (size_t i = 0; i < items.size(); i += ITEM_INTS) out[1] = std::max(out[1], items[i + 2] - items[i + 1]);
-            out[3] = (out[0] + pl.n_strips - 1) / pl.n_strips;
+            out[3] = ((int)items.size() / ITEM_INTS + pl.n_strips - 1) / pl.n_strips;
         }
     }
     out[4] = (int)strip_lds_bytes(MODE_FUSED);
@@ -1333,19 +1340,24 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         }
         return SRCNN_OK;
     }
-    StripParams p{};
-    p.src = d_src;
-    p.src_stride = (long)src_stride;
-    p.src_frame_pitch = (long)src_frame_pitch;
-    p.dst = d_dst;
-    p.pre = d_preclamp;
-    p.dst_stride = (long)dst_stride;
-    p.dst_frame_pitch = (long)dst_frame_pitch;
-    p.width = width;
-    p.height = height;
-    p.row_begin = 0;
-    p.row_end = height;
-    return run_strip(c, MODE_FUSED, p, n_frames);
+    // at most 64 frames per launch: the seam scratch of a launch grows with its frames (25 MB each at 3840x2160)
+    constexpr int kMaxFrames = 64;
+    for (int f0 = 0; f0 < n_frames; f0 += kMaxFrames) {
+        StripParams p{};
+        p.src = d_src + (size_t)f0 * src_frame_pitch;
+        p.src_stride = (long)src_stride;
+        p.src_frame_pitch = (long)src_frame_pitch;
+        p.dst = d_dst + (size_t)f0 * dst_frame_pitch;
+        p.pre = d_preclamp ? d_preclamp + (size_t)f0 * dst_frame_pitch : nullptr;
+        p.dst_stride = (long)dst_stride;
+        p.dst_frame_pitch = (long)dst_frame_pitch;
+        p.width = width;
+        p.height = height;
+        p.row_begin = 0;
+        p.row_end = height;
+        if ((rc = run_strip(c, MODE_FUSED, p, std::min(kMaxFrames, n_frames - f0)))) return rc;
+    }
+    return SRCNN_OK;
 }
 
 int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, int src_row0,

@@ -90,6 +90,8 @@ struct StripParams {
     int seg_rows, n_strips, n_segs; // workgroup decomposition
     const int *items;               // optional explicit work items, ITEM_INTS ints per block: {strip, row_begin,
                                     // row_end, seam above, seam below} (see plan_items()); nullptr = regular grid
+    int items_per_frame;            // a batch repeats the plane's items frame after frame: block b = item b % items_per_frame
+    int seams_per_frame;            // of frame b / items_per_frame, whose seam ids follow those of the frames before it
     float *seam;                    // seam scratch, SEAM_FLOATS * NTHREADS floats per seam (MODE_FUSED, items only)
     float *cseam;                   // column-seam scratch [frame][strip][row][CSEAM_FLOATS]; non-null = strips without column halo
     int strips_total;               // number of strips of the plane (n_strips is 1 in an items launch)

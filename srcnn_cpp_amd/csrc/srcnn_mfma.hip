@@ -172,13 +172,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         // age-based MFMA arbitration, so they run ~12 % faster than the block that joins them later --
         // and the host sizes the items accordingly (measured dispatch order, profiles/r01; speed only:
         // any placement computes the same plane).
-        const int *it = p.items + ITEM_INTS * bid;
+        frame = bid / p.items_per_frame;
+        const int *it = p.items + ITEM_INTS * (bid - frame * p.items_per_frame);
         strip = it[0];
         ys = it[1];
         ye = it[2];
         if constexpr (MODE == MODE_FUSED) {
-            seam_up = it[3];
-            seam_dn = it[4];
+            seam_up = it[3] >= 0 ? it[3] + frame * p.seams_per_frame : -1;
+            seam_dn = it[4] >= 0 ? it[4] + frame * p.seams_per_frame : -1;
         }
         if (ys >= ye) return;      // placeholder (no rows)
     } else {
@@ -580,7 +581,8 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
     __shared__ float ft[SEAM_ROWS][6][FW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
     constexpr int HALO = 2;
-    const int strip = seams[2 * blockIdx.x], b = seams[2 * blockIdx.x + 1];
+    const int frame = blockIdx.x / p.seams_per_frame, sid = blockIdx.x - frame * p.seams_per_frame;
+    const int strip = seams[2 * sid], b = seams[2 * sid + 1];
     const int W = p.width;
     const bool cs = p.cseam != nullptr;
     const int halo_c = cs ? 0 : HALO;
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
     if (cs && wave == 0) {
         const CseamLane cl = cseam_lane(lane);
         for (int r = 0; r < SEAM_ROWS; ++r)
-            cseam_export(&ft[r][0][0], p.cseam + ((long)strip * (p.row_end - p.row_begin) + (b - 2 + r - p.row_begin)) * CSEAM_FLOATS, lane, cl);
+            cseam_export(&ft[r][0][0], p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) + (b - 2 + r - p.row_begin)) * CSEAM_FLOATS, lane, cl);
     }
     const bool px_ok = cs ? (gx < W) && (xi >= 2 || strip == 0) && (xi < FW - 2 || strip == p.strips_total - 1)
                           : (xi >= HALO) && (xi < FW - HALO) && (gx < W);
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
 #pragma unroll
         for (int n = 1; n < 5; ++n) acc += ft[r][n][xn[n]];
         const float v = acc + p.b3;
-        const long o = (long)(b - 2 + r - p.dst_row0) * p.dst_stride + gx;
+        const long o = (long)frame * p.dst_frame_pitch + (long)(b - 2 + r - p.dst_row0) * p.dst_stride + gx;
         p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (PRE) p.pre[o] = v;
     }
@@ -669,7 +671,7 @@ hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, hipStream_t stream)
+hipError_t launch_seams(const StripParams &p, int n_seams /* of all frames */, const int *d_seams, hipStream_t stream)
 {
     if (p.pre) hipLaunchKernelGGL((srcnn_seam_kernel<true>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
     else hipLaunchKernelGGL((srcnn_seam_kernel<false>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);

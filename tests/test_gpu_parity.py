@@ -248,6 +248,32 @@ def test_device_batch_and_unfused_agree(gpu_ctx, weights_blob):
         assert np.array_equal(a[k], m_out)
 
 
+def test_small_batch_repeats_the_item_plan_per_frame(gpu_ctx, weights_blob):
+    """A batch of fewer than 32 frames runs the single-plane work items (row and column seams, no halo rows) frame after
+    frame in ONE launch; every frame must equal the plane computed alone, with padded strides and frame pitches."""
+    torch = _torch()
+    n, h, w = 3, 1080, 1920
+    assert gpu_ctx.query_plan(w, h, n)["workgroups"] == n * gpu_ctx.query_plan(w, h, 1)["workgroups"]
+    frames = synth_batch(w, h, n, first_frame=20)
+    pitch = (h + 3) * (w + 64)
+    d_in = torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+    d_in[:, : h * (w + 64)].view(n, h, w + 64)[:, :, :w] = torch.from_numpy(frames).cuda()
+    d_out = torch.full((n, pitch), 7, dtype=torch.uint8, device="cuda")
+    d_pre = torch.zeros((n, pitch), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.forward_y_dev(d_in.data_ptr(), w + 64, pitch, d_out.data_ptr(), w + 64, pitch, w, h, n, d_pre.data_ptr())
+    gpu_ctx.synchronize()
+    got = d_out[:, : h * (w + 64)].view(n, h, w + 64).cpu().numpy()
+    pre = d_pre[:, : h * (w + 64)].view(n, h, w + 64).cpu().numpy()
+    assert (got[:, :, w:] == 7).all(), "wrote outside the frames' columns"
+    for k in range(n):
+        alone_pre = np.empty((h, w), np.float32)
+        alone = gpu_ctx.forward_y(frames[k], preclamp=alone_pre)
+        assert np.array_equal(got[k, :, :w], alone) and np.array_equal(pre[k, :, :w], alone_pre)
+    m_out, _ = oracle.gpuorder_forward_y(frames[1], weights_blob)
+    assert np.array_equal(got[1, :, :w], m_out)
+
+
 @pytest.mark.parametrize("n_stripes", [2, 3, 8])
 def test_row_stripes_equal_whole_image(gpu_ctx, weights_blob, n_stripes):
     """configs[3] in miniature: row stripes with a 6-row input halo stitch to the
@@ -519,7 +545,9 @@ def test_launch_geometry_reported_by_query_plan(gpu_ctx):
         pytest.skip("a debug knob changes the launch geometry")
     one = gpu_ctx.query_plan(3840, 2160, 1)
     assert one["strips"] == 30 and one["workgroups"] % 2 == 0 and one["workgroups"] >= 256
-    batch = gpu_ctx.query_plan(3840, 2160, 64)
+    batch = gpu_ctx.query_plan(3840, 2160, 64)       # a large batch: regular strip x segment x frame grid
     assert batch["strips"] == 30 and batch["workgroups"] == 30 * batch["segments"] * 64
+    small = gpu_ctx.query_plan(3840, 2160, 8)        # a small batch repeats the plane's work items frame after frame
+    assert small["strips"] == 30 and small["workgroups"] == 8 * one["workgroups"]
     narrow = gpu_ctx.query_plan(130, 700, 1)        # last strip would hold 2 columns: halo columns instead
     assert narrow["strips"] == 2

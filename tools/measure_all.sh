@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-1 measurement sweep on ONE MI355X (run through gpurun); writes JSON lines.
+# Measurement sweep on ONE MI355X (run through gpurun); writes JSON lines.
 # usage: tools/measure_all.sh OUTFILE
 OUT=${1:-gpurun_out/measurements.jsonl}
 : > $OUT
@@ -13,6 +13,8 @@ run --steps 5 --width 5760 --height 3240 --frames 8             # configs[4] fra
 run --steps 20 --width 576 --height 576                         # configs[0] plane on the GPU
 run --steps 5 --path host --frames 32                           # stream of host frames, transfers overlapped
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
+run --steps 3 --warmup 1 --path surface                         # the reference call surface on host buffers (32 f32 planes over PCIe)
+run --steps 20 --width 1920 --height 1080                       # a 1080p plane
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode
 run --steps 50 --mode split16                                   # opt-in split-f16 mode, 1 x 3840x2160

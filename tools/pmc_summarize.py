@@ -4,9 +4,10 @@
 usage: tools/pmc_summarize.py OUTDIR
 Writes OUTDIR/<mode>_4k_pmc_summary.json (counter means per dispatch of the strip kernel and the
 derived figures) and OUTDIR/<mode>_4k_kernel_stats.csv (per-kernel rows of the --stats pass).
-HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 byte-wide loads
-are reported at half their size (calibrated with tools/pmc_calib.hip: profiles/r01/pmc_calibration.txt),
-so reads = FETCH_SIZE * 1024 * 2, writes = WRITE_SIZE * 1024.
+HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
+HALF the bytes of a streaming read whatever its width (byte, dword and dwordx4 loads all calibrated with
+tools/pmc_calib.hip: profiles/r02/pmc_calibration.txt), WRITE_SIZE is exact within 2 %, so
+reads = FETCH_SIZE * 1024 * 2, writes = WRITE_SIZE * 1024 for every kernel.
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -44,8 +45,8 @@ for mode, knames in KERNEL.items():
         d["hbm_bytes_step"] = d["hbm_bytes"]
         for k2 in knames[1:]:
             if extra[k2]:
-                # dword loads / byte stores of the seam kernels: FETCH_SIZE and WRITE_SIZE both exact (pmc_calibration.txt)
-                b = sum(extra[k2][c] / extra_cnt[k2][c] for c in extra[k2]) * 1024
+                # the seam kernels' dword loads are reported at half their size like every read (pmc_calibration.txt)
+                b = sum(extra[k2][c] / extra_cnt[k2][c] * (2 if c == "FETCH_SIZE" else 1) for c in extra[k2]) * 1024
                 d[f"hbm_bytes_{k2}"] = b
                 d["hbm_bytes_step"] += b
     if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
@@ -77,8 +78,53 @@ for mode, knames in KERNEL.items():
         json.dump(summary, fh, indent=1)
     print(mode, json.dumps(d), "avg_ns", avg_ns)
 
+import datetime, subprocess
+try:
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    head = ""
+traffic_rec["_taken_at"] = {"date": datetime.date.today().isoformat(), "commit": head or "unknown (the GPU box holds no .git)"}
+
+# the two reference functions alone (unfused path, one 3840x2160 frame): bytes per launch against the algorithmic 1 + 128 B/pixel
+unf = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc_unfused_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(f, newline="") as fh:
+        for row in csv.DictReader(fh):
+            for tag, name in (("conv99x11_L12", "srcnn_strip_kernel<1"), ("conv55_L3", "srcnn_strip_kernel<2"), ("conv55_cseam", "srcnn_cseam_kernel")):
+                if name in row["Kernel_Name"]:
+                    unf[tag][row["Counter_Name"]].append(float(row["Counter_Value"]))
+if unf:
+    px = 3840 * 2160
+    rec = {}
+    for tag, ctrs in unf.items():
+        m = {k: sum(v) / len(v) for k, v in ctrs.items()}
+        d = {"counters_mean_per_dispatch": m}
+        if "FETCH_SIZE" in m: d["hbm_read_bytes"] = m["FETCH_SIZE"] * 2048
+        if "WRITE_SIZE" in m: d["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
+        if "SQ_INSTS_MFMA" in m and m["SQ_INSTS_MFMA"] > 0:
+            wr = m["SQ_INSTS_MFMA"] / (114 if "L12" in tag else 16)
+            d["wave_rows"] = wr
+            d["non_mfma_valu_per_wave_row"] = (m.get("SQ_INSTS_VALU", 0) - m["SQ_INSTS_MFMA"]) / wr
+            d["lds_insts_per_wave_row"] = m.get("SQ_INSTS_LDS", 0) / wr
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and "GRBM_GUI_ACTIVE" in m:
+            d["mfma_busy_frac_of_simd_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (m["GRBM_GUI_ACTIVE"] / 8)
+        rec[tag] = d
+    if "conv99x11_L12" in rec and "hbm_write_bytes" in rec["conv99x11_L12"]:
+        r = rec["conv99x11_L12"]
+        r["algorithmic_bytes"] = 129 * px
+        r["traffic_over_algorithmic"] = (r.get("hbm_read_bytes", 0) + r["hbm_write_bytes"]) / (129 * px)
+    if "conv55_L3" in rec and "hbm_read_bytes" in rec["conv55_L3"]:
+        r = rec["conv55_L3"]
+        extra = rec.get("conv55_cseam", {})
+        tot = r["hbm_read_bytes"] + r.get("hbm_write_bytes", 0) + extra.get("hbm_read_bytes", 0) + extra.get("hbm_write_bytes", 0)
+        r["algorithmic_bytes"] = 129 * px
+        r["traffic_over_algorithmic"] = tot / (129 * px)
+    with open(os.path.join(out, "unfused_4k_pmc_summary.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print("unfused", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in rec.items()}))
+
 traffic_rec["_note"] = ("per step (one 3840x2160 plane): HBM bytes of the strip kernel plus, in the float32 mode, the two seam kernels; "
-                        "FETCH_SIZE x2 for the strip kernels' byte loads (calibrated: profiles/r01/pmc_calibration.txt) + WRITE_SIZE, KB -> bytes; "
+                        "FETCH_SIZE x2 (every read width is reported at half its size: profiles/r02/pmc_calibration.txt) + WRITE_SIZE, KB -> bytes; "
                         "separate --pmc passes (tools/profile_round.sh); *_mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the strip kernel")
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
     json.dump(traffic_rec, fh, indent=1)

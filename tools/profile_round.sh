@@ -23,6 +23,12 @@ for mode in mfma split16; do
         python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline ) > $OUT/pmc_${mode}_$tag.log 2>&1
   done
 done
+# Convolution99x11 (<1>) and Convolution55 (<2>) alone: HBM bytes (FETCH_SIZE x2, WRITE_SIZE: pmc_calibration.txt) and instruction mix
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  ( cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pmc_unfused_$tag -o pmc -- \
+      python3 $ROOT/bench.py --path unfused --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ) > $OUT/pmc_unfused_$tag.log 2>&1
+done
 # the other kernels: unfused path (layer-1/2 kernel + layer-3 kernel), pipeline byte kernels, exact kernels
 for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20"; do
   set -- $cfg; tag=$1; shift
@@ -30,8 +36,9 @@ for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeli
       python3 $ROOT/bench.py "$@" --warmup 1 --no-cpu-baseline ) > $OUT/trace_$tag.log 2>&1
 done
 tools/measure_all.sh $OUT/measurements.jsonl > /dev/null 2>&1
-python tools/diag_stamps.py > $OUT/diag_stamps_mfma.txt 2>&1
-DIAG_BLOCKS=512 python tools/diag_stamps.py > /dev/null 2>&1
+python tools/diag_light.py > $OUT/diag_light_4k.txt 2>&1
+python tools/diag_light.py 7680 4320 > $OUT/diag_light_8k.txt 2>&1
+python tools/evt_test.py > $OUT/clock_ramp.txt 2>&1
 python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
 python tests/checks/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
 python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
