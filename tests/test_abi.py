@@ -54,6 +54,32 @@ def test_reference_mirror_header_compiles():
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", f"-I{ROOT / 'include'}", str(src)], check=True)
 
 
+def test_reference_mirror_templates_accept_a_cv_mat_shaped_type():
+    """OpenCV is absent from this image, so the templates of srcnn_amd.hpp cannot be instantiated with the real cv::Mat
+    here.  They only use what the reference uses of it: `rows`, `cols`, `data` (uchar*) and `step`, which in OpenCV is
+    a cv::MatStep OBJECT convertible to size_t, not an integer.  Instantiate all four prototypes (and ForwardY) with a
+    type of exactly that shape -- compile only, nothing is called."""
+    import subprocess, tempfile
+    code = r'''
+#include "srcnn_amd.hpp"
+struct MatStepLike { std::size_t p[2]; operator std::size_t() const { return p[0]; } };
+struct MatLike { int flags, dims, rows, cols; unsigned char *data; MatStepLike step; };
+static float k99[64][9][9], b99[64], k11[32][64], b11[32], k55[32][5][5];
+void instantiate(MatLike &y, MatLike &f, std::vector<MatLike> &v32, std::vector<MatLike> &v64) {
+    srcnn::Convolution99(y, f, k99[0], 0.f);                       // src/srcnn.cpp:60-61
+    srcnn::Convolution11(v64, f, k11[0], 0.f);                     // :63-64
+    srcnn::Convolution55(v32, y, k55, 0.f);                        // :66-67
+    srcnn::Convolution99x11(y, v32, k99, b99, k11, b11);           // :69-73
+    srcnn::ForwardY(y, y, k99, b99, k11, b11, k55, 0.f);
+}
+int main() { return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "m.cpp"
+        src.write_text(code)
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)], check=True)
+
+
 def test_create_without_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():
