@@ -416,10 +416,15 @@ struct ItemPlan {
 // `cu_speed` (optional, one factor per CU) scales the estimate per CU.  It is not used in production: feeding back the
 // per-XCD finish times of earlier launches was tried and made things worse -- which XCD runs 1-2 % slow changes from
 // launch to launch (profiles/r02/ablation.txt).  Placement only affects speed: any plan computes the same plane.
-constexpr double kPairFast = 6.85, kPairSlow = 8.35, kAlone = 4.3, kStartFast = 3.0, kStartSlow = 7.2;   // us
+double kPairFast = 6.85, kPairSlow = 8.35, kAlone = 4.3, kStartFast = 3.0, kStartSlow = 7.2;   // us
 
 double cu_finish_estimate(int fast_rows, int slow_rows, double speed)
 {
+    static const bool once = [] {
+        if (const char *e = std::getenv("SRCNN_DEBUG_RATES")) std::sscanf(e, "%lf,%lf,%lf", &kPairFast, &kPairSlow, &kAlone);   // experiment knob
+        return true;
+    }();
+    (void)once;
     const double tf = kStartFast + fast_rows * kPairFast, ts = kStartSlow + slow_rows * kPairSlow;
     double t;
     if (tf <= ts) t = tf + std::max(0.0, slow_rows - (tf - kStartSlow) / kPairSlow) * kAlone;     // the slow one is left alone

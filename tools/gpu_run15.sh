@@ -1,0 +1,6 @@
+#!/bin/bash
+kms() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['roofline']['kernel_ms'], d['roofline']['frac'])"; }
+for R in "6.85,8.35,4.3" "6.88,8.36,5.0" "6.88,8.36,6.0" "6.88,8.36,6.88" "6.9,8.3,5.5" "6.85,8.45,5.5"; do
+  for i in 1 2; do echo -n "rates $R: "; SRCNN_DEBUG_RATES=$R kms --steps 40; done
+done
+for R in "6.85,8.35,4.3" "6.88,8.36,6.0"; do echo -n "1080p rates $R: "; SRCNN_DEBUG_RATES=$R kms --steps 40 --width 1920 --height 1080; echo -n "8K rates $R: "; SRCNN_DEBUG_RATES=$R kms --steps 10 --width 7680 --height 4320; done
