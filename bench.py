@@ -227,7 +227,7 @@ def worker(args):
         # Control plane (barrier, max over ranks, checksum gather): gloo, host tensors.  The data path has
         # no collective for frames; for stripes the 6 halo rows go neighbour to neighbour over RCCL.
         dist.init_process_group("gloo")
-        if args.backend == "nccl":
+        if args.backend == "nccl" and args.workload == "stripe":    # frames exchange nothing: no RCCL communicator is built for them
             try:
                 rccl = dist.new_group(backend="nccl")
                 one = torch.ones(1, device="cuda")

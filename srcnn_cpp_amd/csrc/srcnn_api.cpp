@@ -383,6 +383,8 @@ Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, 
 }
 
 bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0 || h <= 0 || stride < (size_t)w; }
+// the kernels address a lane's plane element with a 32-bit offset from a per-plane scalar base
+bool bad_pitch(size_t plane_pitch) { return plane_pitch >= ((size_t)1 << 29); }
 
 // Explicit work items for a launch that fits the GPU in ONE round with two workgroups per CU.
 // The hardware hands the first n_cu blocks wave slot 0 of every CU; the MFMA pipe is arbitrated by
@@ -1213,7 +1215,7 @@ int srcnn_conv99x11_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, f
     (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_planes, plane_stride, width, height) ||
-        plane_pitch < plane_stride * (size_t)height)
+        plane_pitch < plane_stride * (size_t)height || bad_pitch(plane_pitch))
         return fail(c, SRCNN_ERR_INVALID, "conv99x11_dev: bad plane geometry");
     if (c->mode == SRCNN_MODE_EXACT) {
         HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, 0, d_planes, (long)plane_stride,
@@ -1242,7 +1244,7 @@ int srcnn_conv55_dev(srcnn_ctx *c, const float *d_planes, size_t plane_stride, s
     (void)rc;
     if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
     if (bad_plane(d_planes, plane_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
-        plane_pitch < plane_stride * (size_t)height)
+        plane_pitch < plane_stride * (size_t)height || bad_pitch(plane_pitch))
         return fail(c, SRCNN_ERR_INVALID, "conv55_dev: bad plane geometry");
     if (c->mode == SRCNN_MODE_EXACT) {
         HIP_TRY(c, launch_conv55_exact(d_planes, (long)plane_stride, (long)plane_pitch, 0, d_dst, d_preclamp,
@@ -1277,6 +1279,7 @@ int srcnn_forward_y_unfused_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_s
         return fail(c, SRCNN_ERR_INVALID, "forward_y_unfused_dev: bad arguments");
     static const char *env_plpad = std::getenv("SRCNN_DEBUG_PLPAD");     // experiment: floats added to the plane pitch
     const long pitch = (long)width * height + (env_plpad ? std::atol(env_plpad) : 0);
+    if (bad_pitch((size_t)pitch)) return fail(c, SRCNN_ERR_INVALID, "forward_y_unfused_dev: plane too large");
     if (c->mode == SRCNN_MODE_EXACT) {
         HIP_TRY(c, launch_conv99x11_exact(d_src, (long)src_stride, (long)src_frame_pitch, d_work, width, pitch,
                                           32 * pitch, width, height, n_frames,

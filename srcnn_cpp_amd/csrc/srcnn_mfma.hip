@@ -118,7 +118,7 @@ __device__ __forceinline__ void cseam_export(const float *tile, float *dst, int 
     v = cl.cnt > 1 ? v + b : v;
     v = cl.cnt > 2 ? v + c : v;
     v = cl.cnt > 3 ? v + d : v;
-    if (cl.cnt > 0) dst[e] = v;
+    if (cl.cnt > 0) dst[(unsigned)e] = v;
 }
 
 // ReLU of TWO registers in one instruction.  The host scales layers 1 and 2 by exact powers of two so that every
@@ -203,8 +203,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     const int gx0 = xs - halo_c;                // image column of feature column xi = 0
     // wave 0 exports: address of this lane's slot for output row 0 of the plane (null in the other waves; taking
     // turns among the four waves measured no better)
+    // (a UNIFORM base: the export then stores through a scalar base + the lane's slot, no vector address arithmetic)
     float *cs_row0 = (cs && wave == 0)
-                         ? p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) - p.row_begin) * CSEAM_FLOATS + lane
+                         ? p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) - p.row_begin) * CSEAM_FLOATS
                          : nullptr;
     // A seam (srcnn_kernels.h) replaces the two halo feature rows on that side: the item then computes only its
     // own rows and leaves the two output rows next to the seam to srcnn_seam_kernel.
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     }
     auto load_y = [&](int r) -> uint8_t {
         const int rr = clampi(r, 0, H - 1) - p.src_row0;
-        return srcf[(long)rr * p.src_stride + ycol];
+        const uint8_t *row = srcf + (long)rr * p.src_stride;      // uniform: scalar base + the lane's column
+        return row[(unsigned)ycol];
     };
     auto stage_y = [&](int r, uint8_t v) {
         const int slot = r & (YR - 1);
@@ -284,10 +286,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     const int xi = 32 * wave + j;      // this lane's feature column in the strip
     const int gx = gx0 + xi;           // ... and in the image
 
-    // layer-3 input straight from the 32 planes (MODE_L3)
-    const float *plf = nullptr;
-    if constexpr (MODE == MODE_L3)
-        plf = p.planes_in + (long)frame * p.pl_frame_pitch + clampi(gx, 0, W - 1);
+    // (MODE_L3 takes its layer-3 input straight from the 32 planes: load_planes_at() below)
 
     // ---- layer 3, after the MFMA: vertical sums in registers, horizontal sums through LDS -----
     // out(y,x) = b3 + sum_n F_n(y, clamp(x+n-2)),   F_n(y,x') = sum_m T[5m+n](clamp(y+m-2), x').
@@ -306,16 +305,21 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                    : (xi >= HALO) && (xi < FW - HALO) && (gx < W);
     }
     float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    auto finalize = [&](int y, float acc, bool ok) {
+    // Row offsets that advance by one stride per loop iteration: kept in scalar registers and ADDED to, never
+    // re-multiplied (a 64-bit row * stride product per row lands on the vector ALU), so that every global access of the
+    // row loop is "scalar base + the lane's 32-bit offset".  o_out: output row f - 3 (the row hp_use() finishes in
+    // iteration f); o_src: Y row min(f + 5, H - 1); o_pl: plane row f (MODE_L12 store) / min(f + 1, H - 1) (MODE_L3 load).
+    long o_out = (long)frame * p.dst_frame_pitch + (long)(f_lo - 3 - p.dst_row0) * p.dst_stride;
+    long o_src = (long)(min(f_lo + 5, H - 1) - p.src_row0) * p.src_stride;
+    long o_pl = (long)frame * p.pl_frame_pitch + (long)(MODE == MODE_L3 ? min(f_lo + 1, H - 1) : f_lo) * p.pl_stride;
+    auto finalize = [&](long o, float acc, bool ok) {
         const float v = acc + p.b3;
-        const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
-        // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own
-        // no output pixel store to a scratch word instead of branching around the store.
-        uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
-        *d8 = (uint8_t)clampi((int)v, 0, 255);
+        // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own no output pixel are masked off.
+        uint8_t *row = p.dst + o;
+        if (ok) row[(unsigned)gx] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (PRE) {
-            float *dp = ok ? p.pre + o : p.sink + 64 + lane;
-            *dp = v;
+            float *prow = p.pre + o;
+            if (ok) prow[(unsigned)gx] = v;
         }
     };
     // F tile: [parity of the feature row that completed it][slot][plane n][FW]; slot 0 = output row
@@ -380,9 +384,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         float acc = hv[0];
 #pragma unroll
         for (int n = 1; n < 5; ++n) acc += hv[n];
-        const int y = g - 2 + slot;
-        finalize(y, acc, px_ok && (y >= out_lo) && (y < out_hi));
-        if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, 0, cl);
+        const int y = g - 2 + slot;        // slot > 0 only at the image's last feature row
+        finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && (y >= out_lo) && (y < out_hi));
+        if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, cl);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -392,12 +396,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // MODE_L3 is bound by the 128 B/pixel it reads: the 16 plane loads of row f+1 are issued before
     // row f is consumed, so a whole row of HBM latency hides behind the MFMAs and the row barrier.
     f32x16 d2n = {0};
-    auto load_planes = [&](int f) {
-        const float *q = plf + (long)min(f, H - 1) * p.pl_stride;
+    const unsigned pl_lane = (MODE == MODE_L12) ? (unsigned)(half * p.pl_pitch + gx)
+                                                : (unsigned)(half * p.pl_pitch + clampi(gx, 0, W - 1));   // host: pl_pitch < 2^29
+    auto load_planes_at = [&](long o) {
+        const float *q = p.planes_in + o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d2n[r] = q[(long)(2 * r + half) * p.pl_pitch];
+        for (int r = 0; r < 16; ++r) d2n[r] = (q + (long)(2 * r) * p.pl_pitch)[pl_lane];      // scalar base per plane pair
     };
-    if constexpr (MODE == MODE_L3) load_planes(f_lo);
+    if constexpr (MODE == MODE_L3) load_planes_at((long)frame * p.pl_frame_pitch + (long)f_lo * p.pl_stride);
     for (int f = f_lo; f <= f_end; ++f) {
         unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
         if constexpr (DIAG == 1) dg_a = stamp();
@@ -422,7 +428,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             // here would make the compiler wait for the load right away)
             unsigned ynext = 0;
             if constexpr (!(ABL & 8))
-                if (tid < YP) ynext = load_y(f + 5);
+                if (tid < YP) ynext = (srcf + o_src)[(unsigned)ycol];       // Y row min(f + 5, H - 1)
+            if (f + 5 < H - 1) o_src += p.src_stride;
 
             // ---------------- layer 1: 82 MFMA ------------------------------
             const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
@@ -494,14 +501,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             if constexpr (MODE == MODE_L12) {
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
                 if (gx < W) {
-                    float *o = p.planes_out + (long)frame * p.pl_frame_pitch + (long)f * p.pl_stride + gx;
+                    float *o = p.planes_out + o_pl;      // uniform: plane row f
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[(long)(2 * r + half) * p.pl_pitch] = d2[r];
+                    for (int r = 0; r < 16; ++r) (o + (long)(2 * r) * p.pl_pitch)[pl_lane] = d2[r];
                 }
             }
         } else {
             d2 = d2n;
-            load_planes(f + 1);
+            load_planes_at(o_pl);             // plane row min(f + 1, H - 1)
             if (hp) {
                 hp_load(g, 0);
                 hp_use(g, 0);
@@ -526,6 +533,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             dg_l1 += dg_c - dg_b;
             dg_l23 += dg_d - dg_c;
             dg_bar += e - dg_d;
+        }
+        o_out += p.dst_stride;
+        if constexpr (MODE == MODE_L3) {
+            if (f + 1 < H - 1) o_pl += p.pl_stride;
+        } else {
+            o_pl += p.pl_stride;
         }
     }
     if constexpr (DIAG == 2) lt[2] = __builtin_amdgcn_s_memrealtime();
