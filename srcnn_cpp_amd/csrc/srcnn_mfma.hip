@@ -269,6 +269,23 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         }
         __syncthreads();
     }
+    // The weight fragments must have ARRIVED before the row loop: otherwise the compiler leaves the waits for them
+    // (s_waitcnt vmcnt(35) ... vmcnt(0)) at their first uses inside the layer-1 MFMA stream, where they run again in every
+    // row and make the wave wait there for its just-issued Y load and its last stores.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE != MODE_L3) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int k = 0; k < 41; ++k) asm volatile("" : "+v"(w1f[t][k]));
+#pragma unroll
+        for (int q = 0; q < 32; ++q) asm volatile("" : "+v"(w2f[q]));
+        asm volatile("" : "+v"(b2v));
+    }
+    if constexpr (MODE != MODE_L12) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(w3f[q]));
+    }
 
     // DIAG build only (SRCNN_DEBUG_TUNE & 2): cycle stamps -> p.sink, never an output
     auto stamp = [&]() -> unsigned long long {
