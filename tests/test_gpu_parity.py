@@ -374,6 +374,20 @@ def test_full_size_4k_frame(gpu_ctx, weights_blob):
     check_u8(out, r_out, r_pre)
 
 
+def test_in_place_calls_are_rejected(gpu_ctx):
+    """Every output pixel reads a 13 x 13 input window that other workgroups may already have overwritten: src and dst of
+    the device entry point must not overlap (the reference writes a separate Mat too, src/srcnn.cpp:625-626)."""
+    torch = _torch()
+    w, h = 256, 64
+    buf = torch.zeros((2 * h, w), dtype=torch.uint8, device="cuda")
+    with pytest.raises(S.SrcnnError):
+        gpu_ctx.forward_y_dev(buf.data_ptr(), w, h * w, buf.data_ptr(), w, h * w, w, h, 1)
+    with pytest.raises(S.SrcnnError):                       # partial overlap: dst starts inside src
+        gpu_ctx.forward_y_dev(buf.data_ptr(), w, h * w, buf.data_ptr() + 10 * w, w, h * w, w, h, 1)
+    gpu_ctx.forward_y_dev(buf.data_ptr(), w, h * w, buf.data_ptr() + h * w, w, h * w, w, h, 1)     # adjacent halves: fine
+    gpu_ctx.synchronize()
+
+
 def test_error_paths(gpu_ctx):
     with pytest.raises(S.SrcnnError):
         gpu_ctx.forward_y_dev(0, 10, 100, 0, 10, 100, 10, 10, 1)

@@ -66,9 +66,9 @@ def _worker(rank, world, port, q):
         full = sharding.gather_stripes(out, H, world, rank)
         # the overlapped step (interior rows first, edge bands after the exchange) and its one-launch form
         outs = []
-        for overlap in (True, False):
+        for overlap, via_host in ((True, False), (False, False), (True, True), (False, True)):
             o = torch.zeros_like(mine)
-            sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), overlap=overlap)
+            sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), overlap=overlap, via_host=via_host)
             outs.append(sharding.gather_stripes(o, H, world, rank))
         assert sharding.band_plan(H, world, rank) is not None
         if rank == 0:
