@@ -14,9 +14,12 @@
 //
 //   L1  D1[64ch][32px] = W1aug[64][82] x im2col(Y)[82][32px]     82 MFMA
 //       (81 taps + a constant-1 tap that carries the bias), ReLU
-//   L2  D2[32ch][32px] = W2[32][64]    x D1                      32 MFMA
-//       + bias, ReLU
+//   L2  D2[32ch][32px] = b2 + W2[32][64] x D1                    32 MFMA
+//       (the chain starts from the bias: it is the first MFMA's C operand), ReLU
 //   L3  T [25tap][32px] = W3t[25(32)][32ch] x D2                 16 MFMA
+//
+// Layers 1 and 2 are scaled by exact powers of two (srcnn_kernels.h) so that ReLU is the clamp bit of
+// a packed multiply by 1.0, two registers per instruction; MODE_L12 stores the unscaled map.
 //
 // with v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; each instruction is
 // bit-for-bit a 2-term fmaf chain).  The weights are the A operand (channel /
@@ -48,8 +51,12 @@
 // (130 MFMA x 64 cycles per 32 pixels per SIMD).
 //
 // LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + F tiles 2x3x6x128 f32
-// (18 KiB) = 35 KiB; 243 VGPRs -> two workgroups per CU, i.e. two waves per
-// SIMD, so one wave's non-MFMA instructions are covered by the other's MFMAs.
+// (18 KiB) = 35 KiB; 236 VGPRs -> two workgroups per CU, i.e. two waves per
+// SIMD: while one wave waits (LDS, barrier, a dependent chain's result) the other keeps the matrix
+// pipe busy.  Vector instructions are NOT hidden that way (profiles/r02/ablation.txt): every one
+// inside the MFMA streams costs matrix-pipe time, so the row loop keeps them few -- ReLU packed,
+// bias as accumulator init, row addresses in scalar registers, stores exec-masked.
+// MODE_L3 (HBM-bound) needs only the F tiles and runs four workgroups per CU.
 #include "srcnn_kernels.h"
 
 #include <type_traits>
