@@ -147,7 +147,8 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 // (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output.
 // ABL != 0: timing-only ablation builds (WRONG results by construction; SRCNN_DEBUG_TUNE bits 8..12 select one,
 // profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
-// instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS.
+// instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS, 32 half as many B-operand reads,
+// 64 no column-seam export, 128 no horizontal sums / stores (layer-3 chains kept), 256 no layer-3 chains (horizontal sums kept).
 template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
@@ -410,7 +411,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;        // slot > 0 only at the image's last feature row
         finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && (y >= out_lo) && (y < out_hi));
-        if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, cl);
+        if constexpr (!(ABL & 64))
+            if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, cl);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -477,8 +479,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int s = 0; s < PF; ++s) bq[s] = ldb(s);
 #pragma unroll
                 for (int s = 0; s < 41; ++s) {
-                    if (s + PF < 41) bq[s + PF] = ldb(s + PF);
-                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2)) {
+                    if constexpr (ABL & 32) {          // timing experiment: half as many B-operand reads (odd k-steps reuse the even one's)
+                        if (s + PF < 41) bq[s + PF] = ((s + PF) & 1) ? bq[s + PF - 1] : ldb(s + PF);
+                    } else {
+                        if (s + PF < 41) bq[s + PF] = ldb(s + PF);
+                    }
+                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128)) {
                         if (s == 2) hp_load(g, 0);
                         if (s == 8) hp_use(g, 0);
                     }
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 #pragma unroll
             for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ABL & 2) asm volatile("" ::"v"(t));
+            if constexpr ((ABL & 2) || (ABL & 256)) asm volatile("" ::"v"(t));
             else vertical(f, t);
         }
 
@@ -734,9 +740,9 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
         else if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
 #ifdef SRCNN_ABLATION_BUILD
 #define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, n>), grid, block, lds, stream, p); break;
-        else if ((p.tune >> 8) & 31) {
-            switch ((p.tune >> 8) & 31) {
-                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31)
+        else if ((p.tune >> 8) & 511) {
+            switch ((p.tune >> 8) & 511) {
+                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31) ABL_CASE(32) ABL_CASE(38) ABL_CASE(64) ABL_CASE(128) ABL_CASE(256) ABL_CASE(192)
             default: return hipErrorInvalidValue;
             }
         }
