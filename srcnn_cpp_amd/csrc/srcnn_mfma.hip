@@ -68,6 +68,33 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// Build-time experiment switches (same-box A/B builds, tools/ab.sh; profiles/r02/ablation.txt section 7)
+#ifndef SRCNN_EXP
+#define SRCNN_EXP 0
+#endif
+constexpr int EXP = SRCNN_EXP;
+
+// The first MFMA of a chain whose B operand a packed-multiply (inline asm) has just produced, written as inline asm
+// too: the compiler's hazard recogniser does not count inline-asm statements as wait states, sees the previous chain's
+// last MFMA "right before" this one and pads with s_nop 13 / s_nop 9 (56 / 40 idle cycles per wave-row) although
+// 16 / 8 vector instructions lie between them.
+__device__ __forceinline__ f32x16 mfma_first(float a, float b, const f32x16 &c)
+{
+    if constexpr (EXP & 1) {
+        f32x16 d;
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+        return d;
+    } else {
+        return MFMA(a, b, c);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_first0(float a, float b)      // ... with a zero accumulator
+{
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
@@ -148,7 +175,8 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 // ABL != 0: timing-only ablation builds (WRONG results by construction; SRCNN_DEBUG_TUNE bits 8..12 select one,
 // profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
 // instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS, 32 half as many B-operand reads,
-// 64 no column-seam export, 128 no horizontal sums / stores (layer-3 chains kept), 256 no layer-3 chains (horizontal sums kept).
+// 64 no column-seam export, 128 no horizontal sums / stores (layer-3 chains kept), 256 no layer-3 chains (horizontal sums kept),
+// 512 (with 4) the 24 ReLU instructions as independent single instructions between the layer-1 MFMAs instead of two bursts.
 template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
 __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
@@ -364,7 +392,23 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int m = 1; m < 5; ++m)
                     if (m > r) o[(s * (4 - r) + (m - r - 1)) * NTHREADS] = t[5 * s + m];
         }
-        if (f > 0) {
+        if constexpr (EXP & 4) {
+            // ONE in-place update for every row: the image's top row runs it three times -- rows -2 and -1 replicate row 0
+            // (src/srcnn.cpp:203) -- which builds R[0] = t0, R[1] = t0 + t1, R[2] = (t0 + t1) + t2 with the same additions
+            // as the special case below; the F values of output rows < 0 land in the tile and are never used.
+            const int reps = (f == 0) ? 3 : 1;
+            float *fo = ftile(f, 0) + fplane;
+            for (int q = 0; q < reps; ++q) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    fo[s * FW] = R[3][s] + t[5 * s + 4];
+                    R[3][s] = R[2][s] + t[5 * s + 3];
+                    R[2][s] = R[1][s] + t[5 * s + 2];
+                    R[1][s] = R[0][s] + t[5 * s + 1];
+                    R[0][s] = t[5 * s];
+                }
+            }
+        } else if (f > 0) {
             float *fo = ftile(f, 0) + fplane;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
@@ -430,20 +474,34 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         for (int r = 0; r < 16; ++r) d2n[r] = (q + (long)(2 * r) * p.pl_pitch)[pl_lane];      // scalar base per plane pair
     };
     if constexpr (MODE == MODE_L3) load_planes_at((long)frame * p.pl_frame_pitch + (long)f_lo * p.pl_stride);
-    for (int f = f_lo; f <= f_end; ++f) {
+    // EXP & 2: the B operands of the first PF k-steps of a row (taps 0..5: window row f - 4, staged eight rows ago) are
+    // read BEFORE the row barrier that ends the previous row, so the first MFMA can issue as soon as the barrier releases.
+    constexpr int PF = 3;                         // B operands read PF k-steps ahead
+    float bqn[PF] = {0.f, 0.f, 0.f};
+    auto prefetch_b = [&](int fr) {
+        const float *q = ylds + ((fr - 4) & (YR - 1)) * YP + xi + half;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) bqn[s] = q[2 * s];
+    };
+    if constexpr ((EXP & 2) && MODE != MODE_L3) prefetch_b(f_lo);
+    // EXP & 8: the drain step (the output rows the last feature row completes) sits behind the loop instead of in an
+    // extra iteration of it -- fewer values merge at the loop head, so fewer loop-carried register copies.
+    auto drain = [&](int g) {
+        const int nslots = (g == H - 1) ? 3 : 1;
+        for (int slot = 0; slot < nslots; ++slot) {
+            hp_load(g, slot);
+            hp_use(g, slot);
+        }
+    };
+    const int f_last = (EXP & 8) ? f_hi - 1 : f_end;
+    for (int f = f_lo; f <= f_last; ++f) {
         unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
         if constexpr (DIAG == 1) dg_a = stamp();
-        const bool do_a = f < f_hi;
+        const bool do_a = (EXP & 8) ? true : f < f_hi;
         const int g = f - 1;
         const bool hp = (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 whenever do_a
         if (!do_a) {
-            if (hp) {
-                const int nslots = (g == H - 1) ? 3 : 1;
-                for (int slot = 0; slot < nslots; ++slot) {
-                    hp_load(g, slot);
-                    hp_use(g, slot);
-                }
-            }
+            if (hp) drain(g);
             break;
         }
 
@@ -463,6 +521,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             const float *ybW = yb + (half ? YP - 8 : 0);     // tap 2s = (ki,8), tap 2s+1 = (ki+1,0)
             float abl_b = 1.0f;
             if constexpr (ABL & 16) asm volatile("" : "+v"(abl_b));
+            f32x2 abl_d[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             auto ldb = [&](int s) -> float {
                 if constexpr (ABL & 16) return abl_b;
                 const int ki = (2 * s) / 9, kj = (2 * s) % 9;
@@ -473,10 +532,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             f32x16 a0 = {0}, a1 = {0};
             auto layer1 = [&](auto with_pb) {
                 constexpr bool PB = decltype(with_pb)::value;
-                constexpr int PF = 3;                         // B operands read PF k-steps ahead
                 float bq[41];
 #pragma unroll
-                for (int s = 0; s < PF; ++s) bq[s] = ldb(s);
+                for (int s = 0; s < PF; ++s) bq[s] = (EXP & 2) ? bqn[s] : ldb(s);
 #pragma unroll
                 for (int s = 0; s < 41; ++s) {
                     if constexpr (ABL & 32) {          // timing experiment: half as many B-operand reads (odd k-steps reuse the even one's)
@@ -484,11 +542,27 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                     } else {
                         if (s + PF < 41) bq[s + PF] = ldb(s + PF);
                     }
-                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128)) {
+                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128) && !(EXP & 64)) {
                         if (s == 2) hp_load(g, 0);
                         if (s == 8) hp_use(g, 0);
                     }
+                    if constexpr ((ABL & 1024) != 0) {   // timing experiment (with 256): the 12 chain adds + 3 F-tile writes inside the layer-1 stream
+                        if (s == 14) {
+                            float *fo = ftile(f, 0) + 3 * half * FW + xi;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                fo[c * FW] = R[3][c] + bq[s];
+                                R[3][c] = R[2][c] + bq[s + 1];
+                                R[2][c] = R[1][c] + bq[s + 2];
+                                R[1][c] = R[0][c] + bq[s];
+                                R[0][c] = bq[s + 1];
+                            }
+                        }
+                    }
                     a0 = MFMA(w1f[0][s], bq[s], a0);
+                    if constexpr (ABL & 512) {         // timing experiment: the 24 ReLU instructions as single, independent ones between the MFMAs
+                        if (s >= 8 && s < 32) asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(abl_d[s & 3]) : "s"(ones));
+                    }
                     a1 = MFMA(w1f[1][s], bq[s], a1);
                     // keep this k-step's LDS traffic / horizontal-sum slice where it is
                     __builtin_amdgcn_sched_barrier(0);
@@ -508,7 +582,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             __builtin_amdgcn_sched_barrier(0);
 
             // ---------------- layer 2: 32 MFMA, one back-to-back chain that starts from the bias ------------
-            d2 = MFMA(w2f[0], a0[0], b2v);
+            d2 = mfma_first(w2f[0], a0[0], b2v);
 #pragma unroll
             for (int r = 1; r < 16; ++r) d2 = MFMA(w2f[r], a0[r], d2);
 #pragma unroll
@@ -527,6 +601,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             asm volatile("" : "+v"(ynext));
             if constexpr (!(ABL & 8))
                 if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
+            if constexpr (EXP & 2) prefetch_b(f + 1);
 
             if constexpr (MODE == MODE_L12) {
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
@@ -546,13 +621,29 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         }
 
         if constexpr (MODE != MODE_L12) {
+            // EXP & 64: the horizontal sum / store of the previous row as ONE burst behind the layer-3 MFMAs (its LDS reads in
+            // front of them) instead of inside the layer-1 stream: a vector instruction BETWEEN MFMAs costs ~11 cycles of
+            // matrix-pipe time, one in a burst outside an MFMA stream ~3 (profiles/r02/ablation.txt section 7).
+            if constexpr ((EXP & 64) && MODE == MODE_FUSED) {
+                if (hp) hp_load(g, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // ---------------- layer 3 tap partials: 16 MFMA ------------------
             f32x16 t = {0};
+            if constexpr ((EXP & 1) && MODE == MODE_FUSED) {
+                t = mfma_first0(w3f[0], d2[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
+                for (int r = 1; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((ABL & 2) || (ABL & 256)) asm volatile("" ::"v"(t));
             else vertical(f, t);
+            if constexpr ((EXP & 64) && MODE == MODE_FUSED) {
+                if (hp) hp_use(g, 0);
+            }
         }
 
         if constexpr (DIAG == 1) dg_d = stamp();
@@ -570,6 +661,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         } else {
             o_pl += p.pl_stride;
         }
+    }
+    if constexpr ((EXP & 8) && MODE != MODE_L12) {
+        if (f_hi > f_lo) drain(f_hi - 1);
     }
     if constexpr (DIAG == 2) lt[2] = __builtin_amdgcn_s_memrealtime();
     if (bot_open) {
@@ -740,9 +834,9 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
         else if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
 #ifdef SRCNN_ABLATION_BUILD
 #define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, n>), grid, block, lds, stream, p); break;
-        else if ((p.tune >> 8) & 511) {
-            switch ((p.tune >> 8) & 511) {
-                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31) ABL_CASE(32) ABL_CASE(38) ABL_CASE(64) ABL_CASE(128) ABL_CASE(256) ABL_CASE(192)
+        else if ((p.tune >> 8) & 2047) {
+            switch ((p.tune >> 8) & 2047) {
+                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31) ABL_CASE(32) ABL_CASE(38) ABL_CASE(64) ABL_CASE(128) ABL_CASE(256) ABL_CASE(192) ABL_CASE(516) ABL_CASE(1280)
             default: return hipErrorInvalidValue;
             }
         }
