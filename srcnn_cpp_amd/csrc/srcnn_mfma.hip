@@ -80,13 +80,9 @@ constexpr int EXP = SRCNN_EXP;
 // 16 / 8 vector instructions lie between them.
 __device__ __forceinline__ f32x16 mfma_first(float a, float b, const f32x16 &c)
 {
-    if constexpr (EXP & 1) {
-        f32x16 d;
-        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
-        return d;
-    } else {
-        return MFMA(a, b, c);
-    }
+    f32x16 d;
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 __device__ __forceinline__ f32x16 mfma_first0(float a, float b)      // ... with a zero accumulator
 {
@@ -233,7 +229,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 
     // column seams (srcnn_kernels.h): the strip outputs all FW columns, its four edge pixels are finished elsewhere
     const bool cs = (MODE != MODE_L12) && p.cseam != nullptr;
-    const CseamLane cl = cseam_lane((cs && threadIdx.x < 15) ? (int)threadIdx.x : 15);
+    // export slots: lanes 0..14 of wave 0 (and, for the two-rows-at-once form of the FAST body, lanes 32..46 as well)
+    const CseamLane cl = cseam_lane((cs && threadIdx.x < 64 && (threadIdx.x & 31) < 15 &&
+                                     (threadIdx.x < 32 || (MODE == MODE_FUSED && !PRE && DIAG == 0 && ABL == 0 && !(EXP & 1))))
+                                        ? (int)(threadIdx.x & 31) : 15);
     const int halo_c = cs ? 0 : HALO;
     const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
     const int gx0 = xs - halo_c;                // image column of feature column xi = 0
@@ -349,13 +348,31 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // register chain: R[k][s] = taps m=0..k of the output row that is k+1 rows behind completion.
     // Only the 5 finished values F_n per pixel cross lanes, through a double-buffered LDS tile;
     // that 5-term shifted sum of the previous row runs inside the layer-1 MFMA stream of this row.
+    // FASTK kernels (the production fused kernel) run their steady-state rows through a FAST row body, unrolled over four
+    // rows with everything that depends on f & 3 a compile-time constant: the F-tile slot (LDS offsets become immediates), one
+    // in-place chain update without the image-top / image-bottom / seam-export cases, and the horizontal sums, stores and
+    // column-seam exports of TWO finished rows at once every second row -- lane-half 0 takes output row f - 3, lane-half 1
+    // row f - 4 (in the general body both halves compute the same row).  The rows at either end of a work item (the first six,
+    // which export to the seam above or see the image top, and whatever is left behind the last multiple of four, including the
+    // image's bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
+    constexpr bool FASTK = (MODE == MODE_FUSED) && !PRE && DIAG == 0 && ABL == 0 && !(EXP & 1);
+    constexpr int FSLOT = 6 * FW;                 // floats per F-tile slot
     int xn[5] = {0, 0, 0, 0, 0};
     bool px_ok = false;
     if constexpr (MODE != MODE_L12) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+        for (int n = 0; n < 5; ++n) {
+            xn[n] = clampi(clampi(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
+            // FASTK: the offset of F_n inside a slot, lane-half 1 one slot further (its row of the pair)
+            if constexpr (FASTK) xn[n] += n * FW + half * FSLOT;
+        }
         px_ok = cs ? (gx < W) && (xi >= 2 || strip == 0) && (xi < FW - 2 || strip == p.strips_total - 1)
                    : (xi >= HALO) && (xi < FW - HALO) && (gx < W);
+    }
+    CseamLane cl2 = cl;                           // FASTK: export offsets with lane-half 1 one slot further
+    if constexpr (FASTK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cl2.off[i] += half * FSLOT;
     }
     float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
     // Row offsets that advance by one stride per loop iteration: kept in scalar registers and ADDED to, never
@@ -375,9 +392,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             if (ok) prow[(unsigned)gx] = v;
         }
     };
-    // F tile: [parity of the feature row that completed it][slot][plane n][FW]; slot 0 = output row
+    // F tile.  FASTK: a ring of four slots, feature row g (+ slot for the two extra rows the image's last feature row
+    // completes) in slot {0, 3, 2, 1}[(g + slot) & 3], so that an even row and the odd row before it are neighbours.
+    // Otherwise [parity of the feature row that completed it][slot][plane n][FW]; slot 0 = output row
     // g-2, slots 1,2 = rows g-1, g, which only the image's last feature row g = H-1 completes.
-    auto ftile = [&](int g, int slot) -> float * { return fbuf + (((g & 1) * 3 + slot) * 6) * FW; };
+    auto ftile = [&](int g, int slot) -> float * {
+        if constexpr (FASTK) return fbuf + ((4 - ((g + slot) & 3)) & 3) * FSLOT;
+        else return fbuf + (((g & 1) * 3 + slot) * 6) * FW;
+    };
     // After the layer-3 MFMAs of feature row f: advance the chains, emit the finished F values.
     auto vertical = [&](int f, const f32x16 &t) {
         const int fplane = 3 * half * FW + xi;              // half 0 -> planes 0..2, half 1 -> planes 3..5
@@ -392,23 +414,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int m = 1; m < 5; ++m)
                     if (m > r) o[(s * (4 - r) + (m - r - 1)) * NTHREADS] = t[5 * s + m];
         }
-        if constexpr (EXP & 4) {
-            // ONE in-place update for every row: the image's top row runs it three times -- rows -2 and -1 replicate row 0
-            // (src/srcnn.cpp:203) -- which builds R[0] = t0, R[1] = t0 + t1, R[2] = (t0 + t1) + t2 with the same additions
-            // as the special case below; the F values of output rows < 0 land in the tile and are never used.
-            const int reps = (f == 0) ? 3 : 1;
-            float *fo = ftile(f, 0) + fplane;
-            for (int q = 0; q < reps; ++q) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    fo[s * FW] = R[3][s] + t[5 * s + 4];
-                    R[3][s] = R[2][s] + t[5 * s + 3];
-                    R[2][s] = R[1][s] + t[5 * s + 2];
-                    R[1][s] = R[0][s] + t[5 * s + 1];
-                    R[0][s] = t[5 * s];
-                }
-            }
-        } else if (f > 0) {
+        if (f > 0) {
             float *fo = ftile(f, 0) + fplane;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
@@ -443,26 +449,54 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // Horizontal 5-term sum of one finished output row, split in a load and a use half so it can sit
     // inside the layer-1 MFMA stream with its LDS latency hidden.  Rows outside the segment and lanes
     // without an output pixel store to the scratch word.
+    // (FASTK: the offsets of lane-half 1 point one slot further, so in this one-row form only lane-half 0 counts.)
     float hv[5];
     auto hp_load = [&](int g, int slot) {
         const float *fr = ftile(g, slot);
 #pragma unroll
-        for (int n = 0; n < 5; ++n) hv[n] = fr[n * FW + xn[n]];
+        for (int n = 0; n < 5; ++n) hv[n] = FASTK ? fr[xn[n]] : fr[n * FW + xn[n]];
     };
     auto hp_use = [&](int g, int slot) {
         float acc = hv[0];
 #pragma unroll
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;        // slot > 0 only at the image's last feature row
-        finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && (y >= out_lo) && (y < out_hi));
+        const bool rows_ok = (y >= out_lo) && (y < out_hi) && (!FASTK || half == 0);
+        finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && rows_ok);
         if constexpr (!(ABL & 64))
-            if (cs_row0 && (y >= out_lo) && (y < out_hi)) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, cl);
+            if (cs_row0 && rows_ok) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, FASTK ? cl2 : cl);
+    };
+    // FAST body, odd rows: output rows f - 3 (lane-half 0, F slot SLOT) and f - 4 (lane-half 1, slot SLOT + 1) together.
+    // Both lie inside [out_lo, out_hi) for every row the FAST body runs on.
+    const unsigned st2 = (unsigned)gx + (half ? 0u : (unsigned)p.dst_stride);      // offset from the start of row f - 4
+    const unsigned cs2 = (unsigned)(lane & 31) + (half ? 0u : (unsigned)CSEAM_FLOATS);
+    auto hp2_load = [&](int slot) {
+        const float *fr = fbuf + slot * FSLOT;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) hv[n] = fr[xn[n]];
+    };
+    auto hp2_use = [&](int f, int slot) {
+        float acc = hv[0];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) acc += hv[n];
+        const float v = acc + p.b3;
+        uint8_t *row = p.dst + (o_out - p.dst_stride);        // uniform: output row f - 4
+        if (px_ok) row[st2] = (uint8_t)clampi((int)v, 0, 255);
+        if (cs_row0) {
+            const float *tile = fbuf + slot * FSLOT;
+            const float a = tile[cl2.off[0]], b = tile[cl2.off[1]], c = tile[cl2.off[2]], d = tile[cl2.off[3]];
+            float e = a;
+            e = cl2.cnt > 1 ? e + b : e;
+            e = cl2.cnt > 2 ? e + c : e;
+            e = cl2.cnt > 3 ? e + d : e;
+            float *dst = cs_row0 + (f - 4) * CSEAM_FLOATS;     // uniform: the export row of output row f - 4
+            if (cl2.cnt > 0) dst[cs2] = e;
+        }
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
-    // MFMA stream, finishes the output row that feature row f-1 completed; one extra iteration
-    // drains the last row(s).  One barrier per row.
-    const int f_end = (MODE == MODE_L12) ? f_hi - 1 : f_hi;
+    // MFMA stream, finishes the output row that feature row f-1 completed; a drain step behind the loop
+    // finishes the last row(s).  One barrier per row.
     // MODE_L3 is bound by the 128 B/pixel it reads: the 16 plane loads of row f+1 are issued before
     // row f is consumed, so a whole row of HBM latency hides behind the MFMAs and the row barrier.
     f32x16 d2n = {0};
@@ -474,18 +508,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         for (int r = 0; r < 16; ++r) d2n[r] = (q + (long)(2 * r) * p.pl_pitch)[pl_lane];      // scalar base per plane pair
     };
     if constexpr (MODE == MODE_L3) load_planes_at((long)frame * p.pl_frame_pitch + (long)f_lo * p.pl_stride);
-    // EXP & 2: the B operands of the first PF k-steps of a row (taps 0..5: window row f - 4, staged eight rows ago) are
-    // read BEFORE the row barrier that ends the previous row, so the first MFMA can issue as soon as the barrier releases.
-    constexpr int PF = 3;                         // B operands read PF k-steps ahead
-    float bqn[PF] = {0.f, 0.f, 0.f};
-    auto prefetch_b = [&](int fr) {
-        const float *q = ylds + ((fr - 4) & (YR - 1)) * YP + xi + half;
-#pragma unroll
-        for (int s = 0; s < PF; ++s) bqn[s] = q[2 * s];
-    };
-    if constexpr ((EXP & 2) && MODE != MODE_L3) prefetch_b(f_lo);
-    // EXP & 8: the drain step (the output rows the last feature row completes) sits behind the loop instead of in an
-    // extra iteration of it -- fewer values merge at the loop head, so fewer loop-carried register copies.
+    // The drain step (the output rows the last feature row completes) sits behind the loop, not in an extra iteration
+    // of it: fewer values merge at the loop head, so fewer loop-carried register copies.
     auto drain = [&](int g) {
         const int nslots = (g == H - 1) ? 3 : 1;
         for (int slot = 0; slot < nslots; ++slot) {
@@ -493,17 +517,16 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             hp_use(g, slot);
         }
     };
-    const int f_last = (EXP & 8) ? f_hi - 1 : f_end;
-    for (int f = f_lo; f <= f_last; ++f) {
-        unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
+    unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
+    // One row.  PH < 0: the general body; PH = 0..3: the FAST body for a row with f & 3 == PH (FASTK kernels only).
+    auto row = [&](int f, auto ph_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool FAST = PH >= 0;
         if constexpr (DIAG == 1) dg_a = stamp();
-        const bool do_a = (EXP & 8) ? true : f < f_hi;
         const int g = f - 1;
-        const bool hp = (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 whenever do_a
-        if (!do_a) {
-            if (hp) drain(g);
-            break;
-        }
+        const bool hp = FAST ? (PH & 1) != 0 : (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 inside the loop
+        constexpr int SLOT_W = (4 - PH) & 3;              // FAST: the slot feature row f writes
+        constexpr int SLOT_R = (4 - ((PH + 3) & 3)) & 3;  // FAST, odd rows: the slot of feature row f - 1 (row f - 2: the next one)
 
         f32x16 d2;
         if constexpr (MODE != MODE_L3) {
@@ -532,9 +555,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             f32x16 a0 = {0}, a1 = {0};
             auto layer1 = [&](auto with_pb) {
                 constexpr bool PB = decltype(with_pb)::value;
+                constexpr int PF = 3;                         // B operands read PF k-steps ahead
                 float bq[41];
 #pragma unroll
-                for (int s = 0; s < PF; ++s) bq[s] = (EXP & 2) ? bqn[s] : ldb(s);
+                for (int s = 0; s < PF; ++s) bq[s] = ldb(s);
 #pragma unroll
                 for (int s = 0; s < 41; ++s) {
                     if constexpr (ABL & 32) {          // timing experiment: half as many B-operand reads (odd k-steps reuse the even one's)
@@ -542,9 +566,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                     } else {
                         if (s + PF < 41) bq[s + PF] = ldb(s + PF);
                     }
-                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128) && !(EXP & 64)) {
-                        if (s == 2) hp_load(g, 0);
-                        if (s == 8) hp_use(g, 0);
+                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128)) {
+                        if constexpr (FAST) {
+                            if (s == 2) hp2_load(SLOT_R);
+                            if (s == 8) hp2_use(f, SLOT_R);
+                        } else {
+                            if (s == 2) hp_load(g, 0);
+                            if (s == 8) hp_use(g, 0);
+                        }
                     }
                     if constexpr ((ABL & 1024) != 0) {   // timing experiment (with 256): the 12 chain adds + 3 F-tile writes inside the layer-1 stream
                         if (s == 14) {
@@ -569,8 +598,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 }
             };
             if constexpr (DIAG == 1) dg_b = stamp();
-            if (hp) layer1(std::true_type{});
-            else layer1(std::false_type{});
+            if constexpr (FAST) {
+                layer1(std::integral_constant<bool, (PH & 1) != 0>{});
+            } else {
+                if (hp) layer1(std::true_type{});
+                else layer1(std::false_type{});
+            }
             if constexpr (DIAG == 1) dg_c = stamp();
             // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
             // dependent MFMAs breaks their back-to-back issue (~64 -> ~81 cycles per MFMA,
@@ -601,7 +634,6 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             asm volatile("" : "+v"(ynext));
             if constexpr (!(ABL & 8))
                 if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
-            if constexpr (EXP & 2) prefetch_b(f + 1);
 
             if constexpr (MODE == MODE_L12) {
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
@@ -621,16 +653,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         }
 
         if constexpr (MODE != MODE_L12) {
-            // EXP & 64: the horizontal sum / store of the previous row as ONE burst behind the layer-3 MFMAs (its LDS reads in
-            // front of them) instead of inside the layer-1 stream: a vector instruction BETWEEN MFMAs costs ~11 cycles of
-            // matrix-pipe time, one in a burst outside an MFMA stream ~3 (profiles/r02/ablation.txt section 7).
-            if constexpr ((EXP & 64) && MODE == MODE_FUSED) {
-                if (hp) hp_load(g, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
             // ---------------- layer 3 tap partials: 16 MFMA ------------------
             f32x16 t = {0};
-            if constexpr ((EXP & 1) && MODE == MODE_FUSED) {
+            if constexpr (MODE == MODE_FUSED) {
                 t = mfma_first0(w3f[0], d2[0]);
 #pragma unroll
                 for (int r = 1; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
@@ -639,15 +664,31 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((ABL & 2) || (ABL & 256)) asm volatile("" ::"v"(t));
-            else vertical(f, t);
-            if constexpr ((EXP & 64) && MODE == MODE_FUSED) {
-                if (hp) hp_use(g, 0);
+            if constexpr ((ABL & 2) || (ABL & 256)) {
+                asm volatile("" ::"v"(t));
+            } else if constexpr (FAST) {
+                float *fo = fbuf + SLOT_W * FSLOT + 3 * half * FW + xi;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    fo[s * FW] = R[3][s] + t[5 * s + 4];
+                    R[3][s] = R[2][s] + t[5 * s + 3];
+                    R[2][s] = R[1][s] + t[5 * s + 2];
+                    R[1][s] = R[0][s] + t[5 * s + 1];
+                    R[0][s] = t[5 * s];
+                    // pin the update HERE: left alone, the optimiser sinks the adds into the next row (their first use)
+                    // and keeps the 16 registers of t alive across the barrier
+                    asm volatile("" : "+v"(R[0][s]), "+v"(R[1][s]), "+v"(R[2][s]), "+v"(R[3][s]));
+                }
+            } else {
+                vertical(f, t);
             }
         }
 
         if constexpr (DIAG == 1) dg_d = stamp();
+        // (nothing moves across the row barrier: the unrolled FAST rows would otherwise trade instructions -- and live registers)
+        if constexpr (FASTK) __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(ABL & 1)) lds_barrier();
+        if constexpr (FASTK) __builtin_amdgcn_sched_barrier(0);
         if constexpr (DIAG == 1) {
             const unsigned long long e = stamp();
             dg_top += dg_b - dg_a;
@@ -661,8 +702,25 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         } else {
             o_pl += p.pl_stride;
         }
+    };
+    {
+        int f = f_lo;
+        if constexpr (FASTK) {
+            // FAST rows: [f_a, f_b), both multiples of four, f_a >= f_lo + 6 (behind the seam-export rows and the image top,
+            // and late enough for output rows f - 4 to belong to this item), f_b <= f_hi and <= H - 1 (not the image's last row)
+            const int f_a = (f_lo + 6 + 3) & ~3;
+            const int f_b = min(f_hi, H - 1) & ~3;
+            for (; f < f_hi && f < f_a; ++f) row(f, std::integral_constant<int, -1>{});
+            for (; f + 4 <= f_b; f += 4) {
+                row(f, std::integral_constant<int, 0>{});
+                row(f + 1, std::integral_constant<int, 1>{});
+                row(f + 2, std::integral_constant<int, 2>{});
+                row(f + 3, std::integral_constant<int, 3>{});
+            }
+        }
+        for (; f < f_hi; ++f) row(f, std::integral_constant<int, -1>{});
     }
-    if constexpr ((EXP & 8) && MODE != MODE_L12) {
+    if constexpr (MODE != MODE_L12) {
         if (f_hi > f_lo) drain(f_hi - 1);
     }
     if constexpr (DIAG == 2) lt[2] = __builtin_amdgcn_s_memrealtime();
