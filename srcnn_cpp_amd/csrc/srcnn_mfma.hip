@@ -94,6 +94,26 @@ __device__ __forceinline__ f32x16 mfma_first0(float a, float b)      // ... with
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
+// A UNIFORM pointer the optimiser cannot look through.  "scalar base + the lane's 32-bit offset" is one global instruction
+// (saddr form) only while the 64-bit base stays a scalar; left visible, base + offset is re-associated into a 64-bit vector
+// add (v_lshl_add_u64) per access.
+// ... and the lane's 32-bit offset, kept 32 bits wide up to the access (hoisted out of the row loop as a zero-extended
+// 64-bit pair it no longer matches the saddr form either).
+__device__ __forceinline__ unsigned lane_off(unsigned x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T *scalar_base(T *p)
+{
+    // (a pointer to GLOBAL memory: behind the asm the optimiser can no longer infer that from the kernel argument, and a
+    // generic pointer would turn the access into a flat_ instruction)
+    __attribute__((address_space(1))) T *g = (__attribute__((address_space(1))) T *)p;
+    asm volatile("" : "+s"(g));
+    return g;
+}
+
 // Row barrier.  The waves of a workgroup only exchange data through LDS, so the barrier has to
 // order LDS traffic only: __syncthreads() would also wait for every outstanding global store and
 // load (s_waitcnt vmcnt(0)) on every row, which stalls MODE_L12 behind its 16 plane stores per row.
@@ -385,8 +405,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     auto finalize = [&](long o, float acc, bool ok) {
         const float v = acc + p.b3;
         // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own no output pixel are masked off.
-        uint8_t *row = p.dst + o;
-        if (ok) row[(unsigned)gx] = (uint8_t)clampi((int)v, 0, 255);
+        auto row = scalar_base(p.dst + o);
+        if (ok) row[lane_off((unsigned)gx)] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (PRE) {
             float *prow = p.pre + o;
             if (ok) prow[(unsigned)gx] = v;
@@ -470,6 +490,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // Both lie inside [out_lo, out_hi) for every row the FAST body runs on.
     const unsigned st2 = (unsigned)gx + (half ? 0u : (unsigned)p.dst_stride);      // offset from the start of row f - 4
     const unsigned cs2 = (unsigned)(lane & 31) + (half ? 0u : (unsigned)CSEAM_FLOATS);
+    const int do_cs = __builtin_amdgcn_readfirstlane((cs && wave == 0) ? 1 : 0);     // a scalar, not a lane mask
     auto hp2_load = [&](int slot) {
         const float *fr = fbuf + slot * FSLOT;
 #pragma unroll
@@ -480,16 +501,16 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 #pragma unroll
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const float v = acc + p.b3;
-        uint8_t *row = p.dst + (o_out - p.dst_stride);        // uniform: output row f - 4
-        if (px_ok) row[st2] = (uint8_t)clampi((int)v, 0, 255);
-        if (cs_row0) {
+        auto row = scalar_base(p.dst + (o_out - p.dst_stride));        // uniform: output row f - 4
+        if (px_ok) row[lane_off(st2)] = (uint8_t)clampi((int)v, 0, 255);
+        if (do_cs) {
             const float *tile = fbuf + slot * FSLOT;
             const float a = tile[cl2.off[0]], b = tile[cl2.off[1]], c = tile[cl2.off[2]], d = tile[cl2.off[3]];
             float e = a;
             e = cl2.cnt > 1 ? e + b : e;
             e = cl2.cnt > 2 ? e + c : e;
             e = cl2.cnt > 3 ? e + d : e;
-            float *dst = cs_row0 + (f - 4) * CSEAM_FLOATS;     // uniform: the export row of output row f - 4
+            auto dst = scalar_base(cs_row0 + (f - 4) * CSEAM_FLOATS);     // uniform: the export row of output row f - 4
             if (cl2.cnt > 0) dst[cs2] = e;
         }
     };
@@ -504,8 +525,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                                                 : (unsigned)(half * p.pl_pitch + clampi(gx, 0, W - 1));   // host: pl_pitch < 2^29
     auto load_planes_at = [&](long o) {
         const float *q = p.planes_in + o;
+        const unsigned lo = lane_off(pl_lane * 4u);       // BYTE offset, 32 bits (host: pl_pitch < 2^29)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d2n[r] = (q + (long)(2 * r) * p.pl_pitch)[pl_lane];      // scalar base per plane pair
+        for (int r = 0; r < 16; ++r)                      // scalar base per plane pair
+            d2n[r] = *(const __attribute__((address_space(1))) float *)((const __attribute__((address_space(1))) char *)scalar_base(q + (long)(2 * r) * p.pl_pitch) + lo);
     };
     if constexpr (MODE == MODE_L3) load_planes_at((long)frame * p.pl_frame_pitch + (long)f_lo * p.pl_stride);
     // The drain step (the output rows the last feature row completes) sits behind the loop, not in an extra iteration
@@ -533,9 +556,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             // prefetch the Y row the NEXT feature row needs
             // (kept as the raw byte until after the MFMA stream: converting it
             // here would make the compiler wait for the load right away)
-            unsigned ynext = 0;
+            unsigned ynext;
+            asm volatile("" : "=v"(ynext));      // (undefined in the lanes that load nothing: no instruction)
             if constexpr (!(ABL & 8))
-                if (tid < YP) ynext = (srcf + o_src)[(unsigned)ycol];       // Y row min(f + 5, H - 1)
+                if (tid < YP) ynext = scalar_base(srcf + o_src)[lane_off((unsigned)ycol)];       // Y row min(f + 5, H - 1)
             if (f + 5 < H - 1) o_src += p.src_stride;
 
             // ---------------- layer 1: 82 MFMA ------------------------------
@@ -639,8 +663,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
                 if (gx < W) {
                     float *o = p.planes_out + o_pl;      // uniform: plane row f
+                    const unsigned lo = lane_off(pl_lane * 4u);       // BYTE offset, 32 bits (host: pl_pitch < 2^29)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) (o + (long)(2 * r) * p.pl_pitch)[pl_lane] = d2[r];
+                    for (int r = 0; r < 16; ++r)
+                        *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)scalar_base(o + (long)(2 * r) * p.pl_pitch) + lo) = d2[r];
                 }
             }
         } else {
