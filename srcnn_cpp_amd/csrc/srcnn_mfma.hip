@@ -185,6 +185,13 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
     }
 }
 
+// Kernels whose steady-state rows run through the FAST row body (see the row loop).  Convolution55 alone (MODE_L3) is
+// bound by its plane loads: the FAST body measured 0-1 % slower there (112 registers instead of 93), so it keeps the general one.
+constexpr bool fast_kernel(int mode, bool pre, int diag, int abl)
+{
+    return mode == MODE_FUSED && !pre && diag == 0 && abl == 0 && !(EXP & 1);
+}
+
 // DIAG: 1 = cycle stamps around every phase of every row (SRCNN_DEBUG_TUNE & 2; perturbs the timing, runs without
 // seams), 2 = four wall-clock stamps per wave -- entry, loop start, loop end, exit -- on the production launch
 // (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output.
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     const bool cs = (MODE != MODE_L12) && p.cseam != nullptr;
     // export slots: lanes 0..14 of wave 0 (and, for the two-rows-at-once form of the FAST body, lanes 32..46 as well)
     const CseamLane cl = cseam_lane((cs && threadIdx.x < 64 && (threadIdx.x & 31) < 15 &&
-                                     (threadIdx.x < 32 || (MODE == MODE_FUSED && !PRE && DIAG == 0 && ABL == 0 && !(EXP & 1))))
+                                     (threadIdx.x < 32 || fast_kernel(MODE, PRE, DIAG, ABL)))
                                         ? (int)(threadIdx.x & 31) : 15);
     const int halo_c = cs ? 0 : HALO;
     const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // row f - 4 (in the general body both halves compute the same row).  The rows at either end of a work item (the first six,
     // which export to the seam above or see the image top, and whatever is left behind the last multiple of four, including the
     // image's bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
-    constexpr bool FASTK = (MODE == MODE_FUSED) && !PRE && DIAG == 0 && ABL == 0 && !(EXP & 1);
+    constexpr bool FASTK = fast_kernel(MODE, PRE, DIAG, ABL);
     constexpr int FSLOT = 6 * FW;                 // floats per F-tile slot
     int xn[5] = {0, 0, 0, 0, 0};
     bool px_ok = false;
@@ -672,7 +679,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         } else {
             d2 = d2n;
             load_planes_at(o_pl);             // plane row min(f + 1, H - 1)
-            if (hp) {
+            if constexpr (FAST) {
+                if constexpr ((PH & 1) != 0) {
+                    hp2_load(SLOT_R);
+                    hp2_use(f, SLOT_R);
+                }
+            } else if (hp) {
                 hp_load(g, 0);
                 hp_use(g, 0);
             }
