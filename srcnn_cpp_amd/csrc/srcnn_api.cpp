@@ -709,6 +709,15 @@ int seam_scratch_for_stream(srcnn_ctx *c, srcnn_ctx::SeamScratch **out)
     return SRCNN_OK;
 }
 
+// Column seams (strips of FW output columns instead of FW - 4 plus two halo columns each side) pay when they save a strip:
+// 3840 = 30 instead of 31, 1920 = 15 instead of 16.  Where the count is the same (576: 5 and 5) they only add the export
+// work and the third kernel launch.
+bool cseam_pays(int width)
+{
+    const int ns_cs = (width + FW - 1) / FW, ns_halo = (width + FW - 5) / (FW - 4);
+    return ns_cs < ns_halo && (width - (ns_cs - 1) * FW >= 4 || ns_cs == 1);
+}
+
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
@@ -772,22 +781,27 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
         const bool want_seams = mode == MODE_FUSED && !split16 && (seam_knob & 1) && !(p.tune & 2);
         int rc;
-        if (want_seams && (seam_knob & 2)) {
+        // a plane too small for two items per CU of useful height: one (taller) item per CU still beats the regular grid
+        // with its halo rows
+        auto items_for = [&](int n_strips_, bool seams_) -> int {
+            int rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, wgs_per_cu, seams_, &table);
+            if (!rc2 && table->count == 0 && wgs_per_cu == 2 && seams_)
+                rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, 1, seams_, &table);
+            return rc2;
+        };
+        bool col_seams = false;
+        if (want_seams && (seam_knob & 2) && cseam_pays(p.width)) {
             // strips of FW output columns; the last strip must hold the 4 columns its left neighbour's pixels need
             const int ns_cs = (p.width + FW - 1) / FW;
-            if (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1) {
-                if ((rc = build_items(c, ns_cs, p.row_begin, p.row_end, wgs_per_cu, true, &table))) return rc;
-                // a plane too small for two items per CU of useful height: one (taller) item per CU still beats
-                // the regular grid with its halo rows
-                if (table->count == 0 && wgs_per_cu == 2 &&
-                    (rc = build_items(c, ns_cs, p.row_begin, p.row_end, 1, true, &table)))
-                    return rc;
-                if (table->count > 0) p.strips_total = ns_cs;
-                else table = nullptr;
+            if ((rc = items_for(ns_cs, true))) return rc;
+            if (table->count > 0) {
+                p.strips_total = ns_cs;
+                col_seams = true;
+            } else {
+                table = nullptr;
             }
         }
-        const bool col_seams = table != nullptr;
-        if (!table && (rc = build_items(c, pl.n_strips, p.row_begin, p.row_end, wgs_per_cu, want_seams, &table))) return rc;
+        if (!table && (rc = items_for(pl.n_strips, want_seams))) return rc;
         grid_items = table->count;
         if (grid_items > 0) {
             p.items = static_cast<const int *>(table->dev.p);
@@ -825,7 +839,8 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     if (fused32 && n_frames > 1 && !(p.tune & 2) && grid_items == 0) {
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
         const int ns_cs = (p.width + FW - 1) / FW;
-        if ((!env_seams || (std::atoi(env_seams) & 2)) && (p.width - (ns_cs - 1) * FW >= 4 || ns_cs == 1)) {
+        (void)ns_cs;
+        if ((!env_seams || (std::atoi(env_seams) & 2)) && cseam_pays(p.width)) {
             pl = make_plan(c, p.width, p.row_end - p.row_begin, n_frames, halo, wgs_per_cu, 0);
             p.seg_rows = pl.seg_rows;
             p.n_strips = pl.n_strips;
@@ -1174,15 +1189,17 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     // mirrors run_strip(): the float32 fused kernel uses column seams (strips of FW columns) when the geometry allows
     const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
     const int ns_cs = (width + FW - 1) / FW;
-    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (n_frames > 1 || (seam_knob & 1)) &&
-                     (width - (ns_cs - 1) * FW >= 4 || ns_cs == 1);
+    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (n_frames > 1 || (seam_knob & 1)) && cseam_pays(width);
     int items_per_cu = wgs_per_cu;
-    if (col_seams && n_frames == 1 &&
-        plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), wgs_per_cu, true).items.empty()) {
-        if (wgs_per_cu == 2 && !plan_items(c->n_cu, ns_cs, 0, height, skew_percent(), 1, true).items.empty())
-            items_per_cu = 1;
-        else
-            col_seams = false;
+    const bool row_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 1);
+    auto fits = [&](int n_strips_, int per_cu) { return !plan_items(c->n_cu, n_strips_, 0, height, skew_percent(), per_cu, row_seams).items.empty(); };
+    if (col_seams && n_frames == 1 && !fits(ns_cs, wgs_per_cu)) {
+        if (wgs_per_cu == 2 && fits(ns_cs, 1)) items_per_cu = 1;
+        else col_seams = false;
+    }
+    if (!col_seams && n_frames == 1 && row_seams && wgs_per_cu == 2) {
+        const int ns_halo = (width + FW - 5) / (FW - 4);
+        if (!fits(ns_halo, 2) && fits(ns_halo, 1)) items_per_cu = 1;
     }
     const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu, col_seams ? 0 : -1);
     out[0] = pl.n_strips * pl.n_segs * n_frames;
