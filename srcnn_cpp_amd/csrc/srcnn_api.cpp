@@ -907,14 +907,17 @@ void cubic_table(int n_src, int n_dst, int *ofs, short *coef)
     }
 }
 
-// Device-side cubic resize of n_planes planes; tables are built on the host and uploaded.
-int resize_planes_dev(srcnn_ctx *c, const uint8_t *src, long sstride, long spitch, int sw, int sh, uint8_t *dst,
-                      long dstride, long dpitch, int dw, int dh, int n_planes)
+// Cubic coefficient tables of a (sw x sh) -> (dw x dh) resize on the device: built on the host and uploaded once for a
+// stream of equally sized frames.  Layout: int xofs[dw], yofs[dh]; short alpha[4 dw], beta[4 dh].
+struct ResizeTables {
+    const int *xofs, *yofs;
+    const short *alpha, *beta;
+};
+int ensure_tables(srcnn_ctx *c, int sw, int sh, int dw, int dh, ResizeTables *t)
 {
     const size_t ints = (size_t)dw + dh, shorts = 4 * ((size_t)dw + dh);
     const size_t bytes = ints * 4 + shorts * 2;
     if (!(c->tables.p && c->tab_sw == sw && c->tab_sh == sh && c->tab_dw == dw && c->tab_dh == dh)) {
-        // a stream of equally sized frames builds and uploads the tables once
         std::vector<unsigned char> host(bytes);
         int *xofs = reinterpret_cast<int *>(host.data()), *yofs = xofs + dw;
         short *alpha = reinterpret_cast<short *>(yofs + dh), *beta = alpha + 4 * (size_t)dw;
@@ -926,10 +929,22 @@ int resize_planes_dev(srcnn_ctx *c, const uint8_t *src, long sstride, long spitc
         HIP_TRY(c, hipMemcpy(c->tables.p, host.data(), bytes, hipMemcpyHostToDevice));
         c->tab_sw = sw; c->tab_sh = sh; c->tab_dw = dw; c->tab_dh = dh;
     }
-    const int *dx = static_cast<const int *>(c->tables.p), *dy = dx + dw;
-    const short *da = reinterpret_cast<const short *>(dy + dh), *db = da + 4 * (size_t)dw;
-    HIP_TRY(c, launch_resize_cubic(src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, n_planes, dx, da, dy,
-                                   db, c->stream));
+    t->xofs = static_cast<const int *>(c->tables.p);
+    t->yofs = t->xofs + dw;
+    t->alpha = reinterpret_cast<const short *>(t->yofs + dh);
+    t->beta = t->alpha + 4 * (size_t)dw;
+    return SRCNN_OK;
+}
+
+// Device-side cubic resize of n_planes planes.
+int resize_planes_dev(srcnn_ctx *c, const uint8_t *src, long sstride, long spitch, int sw, int sh, uint8_t *dst,
+                      long dstride, long dpitch, int dw, int dh, int n_planes)
+{
+    ResizeTables t;
+    int rc;
+    if ((rc = ensure_tables(c, sw, sh, dw, dh, &t))) return rc;
+    HIP_TRY(c, launch_resize_cubic(src, sstride, spitch, sw, sh, dst, dstride, dpitch, dw, dh, n_planes, t.xofs, t.alpha,
+                                   t.yofs, t.beta, c->stream));
     return SRCNN_OK;
 }
 
@@ -946,6 +961,21 @@ int process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int w, in
     if ((rc = reserve(c, c->y_sr, hi))) return rc;
     uint8_t *ycc_lo = static_cast<uint8_t *>(c->ycc_lo.p), *ycc_hi = static_cast<uint8_t *>(c->ycc_hi.p);
     uint8_t *y_sr = static_cast<uint8_t *>(c->y_sr.p);
+    // Two launches around the conv path instead of three (and 54 MB instead of 93 MB at 1080p -> 4K): the colour conversion
+    // happens while the resize stages its source tile, the resized Cr / Cb go straight into the final BGR.  Same integer
+    // arithmetic per value.  SRCNN_DEBUG_PIPE3=1: the three separate kernels (A/B; also the fallback for geometries
+    // outside the tiled resize's limits).
+    static const char *env_pipe3 = std::getenv("SRCNN_DEBUG_PIPE3");
+    if (!(env_pipe3 && std::atoi(env_pipe3)) && fused_pipeline_ok(w, h, ow, oh, ycc_hi, (long)ow, d_out, (long)out_stride)) {
+        ResizeTables t;
+        if ((rc = ensure_tables(c, w, h, ow, oh, &t))) return rc;
+        HIP_TRY(c, launch_bgr_to_y_resized(d_bgr, (long)stride, w, h, ycc_hi, ow, ow, oh, t.xofs, t.alpha, t.yofs, t.beta,
+                                           c->stream));                                            // :509, :540, :568-575 (Y)
+        if ((rc = srcnn_forward_y_dev(c, ycc_hi, ow, hi, y_sr, ow, hi, ow, oh, 1, nullptr))) return rc;           // :609, :627
+        HIP_TRY(c, launch_resize_merge(d_bgr, (long)stride, w, h, y_sr, ow, d_out, (long)out_stride, ow, oh, t.xofs, t.alpha,
+                                       t.yofs, t.beta, c->stream));                                // :576-583 (Cr, Cb), :638-657
+        return SRCNN_OK;
+    }
     HIP_TRY(c, launch_bgr2ycrcb(d_bgr, (long)stride, w, h, ycc_lo, w, (long)lo, c->stream));      // :509, :540
     if ((rc = resize_planes_dev(c, ycc_lo, w, (long)lo, w, h, ycc_hi, ow, (long)hi, ow, oh, 3))) return rc;  // :568-583
     if ((rc = srcnn_forward_y_dev(c, ycc_hi, ow, hi, y_sr, ow, hi, ow, oh, 1, nullptr))) return rc;           // :609, :627

@@ -146,4 +146,12 @@ hipError_t launch_resize_cubic(const uint8_t *src, long sstride, long spitch, in
                                long dstride, long dpitch, int dw, int dh, int n_planes, const int *xofs,
                                const short *alpha, const int *yofs, const short *beta, hipStream_t st);
 
+// the pipeline step in two launches: BGR -> up-sampled Y, and BGR + the conv path's Y -> up-sampled BGR
+bool fused_pipeline_ok(int sw, int sh, int dw, int dh, const void *y_hi, long ystride, const void *out, long ostride);
+hipError_t launch_bgr_to_y_resized(const uint8_t *bgr, long stride, int sw, int sh, uint8_t *dst, long dstride, int dw, int dh,
+                                   const int *xofs, const short *alpha, const int *yofs, const short *beta, hipStream_t st);
+hipError_t launch_resize_merge(const uint8_t *bgr, long stride, int sw, int sh, const uint8_t *ysr, long ystride, uint8_t *out,
+                               long ostride, int dw, int dh, const int *xofs, const short *alpha, const int *yofs,
+                               const short *beta, hipStream_t st);
+
 }  // namespace srcnn

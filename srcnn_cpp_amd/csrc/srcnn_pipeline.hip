@@ -150,6 +150,34 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled_kernel(const uint8_t *
     }
 }
 
+// vertical pass of output row dy, columns dx .. dx+3 (thread tx of the tile), packed one byte per pixel.
+// hbuf holds the horizontal sums as floats (exact); see vresize_px() for the two arithmetic variants.
+__device__ __forceinline__ unsigned vpass4(const float (*hbuf)[256], int tx, int j, const short *__restrict__ b, int dx, int dw)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const f32x4 *>(&hbuf[j + k][4 * tx]);
+    unsigned r = 0;
+    if (dx + 3 < dw - dw % 8) {            // all four columns in the SIMD functor's range: float32, every product and sum rounded
+        const float sc = 1.0f / (2048.0f * 2048.0f);
+        const float b0 = (float)b[0] * sc, b1 = (float)b[1] * sc, b2 = (float)b[2] * sc, b3 = (float)b[3] * sc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = __fmul_rn(h[3][c], b3);
+            v = __fadd_rn(__fmul_rn(h[2][c], b2), v);
+            v = __fadd_rn(__fmul_rn(h[1][c], b1), v);
+            v = __fadd_rn(__fmul_rn(h[0][c], b0), v);
+            r |= (unsigned)sat8(__float2int_rn(v)) << (8 * c);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            r |= vresize_px((int)h[0][c], (int)h[1][c], (int)h[2][c], (int)h[3][c], b[0], b[1], b[2], b[3], dx + c < dw - dw % 8) << (8 * c);
+    }
+    return r;
+}
+
 // Second tiling: a workgroup produces a 256 x 32 output tile and every thread FOUR adjacent pixels of 8 rows, so
 // the vertical pass reads its taps as one 16-byte LDS word per row and stores one dword per row: a quarter of the
 // store and LDS instructions of the kernel above (which remains the fallback for small scales / odd strides).
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t 
                                                                   const int *__restrict__ yofs,
                                                                   const short *__restrict__ beta)
 {
-    __shared__ __attribute__((aligned(16))) int hbuf[RMAX4][256];
+    __shared__ __attribute__((aligned(16))) float hbuf[RMAX4][256];
     __shared__ uint8_t sbuf[RMAX4][SMAX];
     const int tid = threadIdx.x;
     const int dx0 = blockIdx.x * 256;
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t 
             int t = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) t += sbuf[rr][x0 + k] * a[k];
-            hbuf[rr][tid] = t;
+            hbuf[rr][tid] = (float)t;      // exact (|t| < 2^24)
         }
     }
     __syncthreads();
@@ -197,27 +225,174 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t 
     const int tx = tid & 63, ty = tid >> 6;
     const int dx = dx0 + 4 * tx;
     if (dx >= dw) return;
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const bool vec_ok = (dx + 3 < dw);
     for (int r = 0; r < 8; ++r) {
         const int dy = dy0 + 8 * ty + r;
         if (dy >= dy1) break;
-        const int j = yofs[dy] - 1 - r_lo;
-        i32x4 h[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) h[k] = *reinterpret_cast<const i32x4 *>(&hbuf[j + k][4 * tx]);
-        const short *b = beta + 4 * dy;
+        const unsigned v = vpass4(hbuf, tx, yofs[dy] - 1 - r_lo, beta + 4 * dy, dx, dw);
         uint8_t *o = dst + (long)blockIdx.z * dpitch + (long)dy * dstride + dx;
-        unsigned px[4];
+        if (dx + 3 < dw) *reinterpret_cast<unsigned *>(o) = v;
+        else
+            for (int c = 0; c < 4 && dx + c < dw; ++c) o[c] = (uint8_t)(v >> (8 * c));
+    }
+}
+
+// ---- the whole pipeline step in two launches (srcnn_process_bgr[_dev]) ------------------------------------------
+// cvtColor + split + 3 x resize + (conv path) + merge + cvtColor as the reference runs them (src/srcnn.cpp:509-657) touch
+// every plane twice more than needed: the low-resolution Y / Cr / Cb planes only feed the resize, the resized Cr / Cb only
+// the final conversion.  bgr_to_y_resized_kernel converts while it stages its source tile (BGR in, up-sampled Y out);
+// resize_merge_kernel does the same for Cr and Cb and turns them, with the conv path's Y, straight into BGR.  The
+// arithmetic per value is that of the three separate kernels above -- bit-identical -- in the tiled4 layout
+// (256 x 32 output tile per workgroup, four adjacent pixels of eight rows per thread).
+__device__ __forceinline__ int bgr_to_comp(const uint8_t *px, int comp)
+{
+    const int B = px[0], G = px[1], R = px[2];
+    const int Y = descale14(B * 1868 + G * 9617 + R * 4899);
+    if (comp == 0) return sat8(Y);
+    if (comp == 1) return sat8(descale14((R - Y) * 11682 + (128 << 14)));
+    return sat8(descale14((B - Y) * 9241 + (128 << 14)));
+}
+
+struct TileGeom {
+    int dx0, dy0, dy1, r_lo, c_lo, ncol, nrow;
+};
+
+// stage component `comp` of the BGR source tile into sbuf, horizontal pass into hbuf (both barriers included)
+__device__ __forceinline__ void stage_and_hpass(const uint8_t *__restrict__ bgr, long stride, int sw, int sh, int dw, int comp,
+                                                const TileGeom &g, const int *__restrict__ xofs,
+                                                const short *__restrict__ alpha, uint8_t (*sbuf)[SMAX], float (*hbuf)[256])
+{
+    const int tid = threadIdx.x;
+    for (int e = tid; e < g.nrow * g.ncol; e += 256) {
+        const int rr = e / g.ncol, cc = e - rr * g.ncol;
+        sbuf[rr][cc] = (uint8_t)bgr_to_comp(bgr + (long)min(max(g.r_lo + rr, 0), sh - 1) * stride + 3L * min(max(g.c_lo + cc, 0), sw - 1), comp);
+    }
+    __syncthreads();
+    const int dxc = min(g.dx0 + tid, dw - 1);
+    const int x0 = xofs[dxc] - 1 - g.c_lo;
+    int a[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            px[c] = vresize_px(h[0][c], h[1][c], h[2][c], h[3][c], b[0], b[1], b[2], b[3], dx + c < dw - dw % 8);
-        if (vec_ok) {
-            *reinterpret_cast<unsigned *>(o) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-        } else {
-            for (int c = 0; c < 4 && dx + c < dw; ++c) o[c] = (uint8_t)px[c];
+    for (int k = 0; k < 4; ++k) a[k] = alpha[4 * dxc + k];
+    for (int rr = 0; rr < g.nrow; ++rr) {
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t += sbuf[rr][x0 + k] * a[k];
+        hbuf[rr][tid] = (float)t;          // |t| < 2^24: exact; converted once per source row instead of once per output row
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ TileGeom tile_geom(int dw, int dh, const int *__restrict__ xofs, const int *__restrict__ yofs)
+{
+    TileGeom g;
+    g.dx0 = blockIdx.x * 256;
+    g.dy0 = blockIdx.y * RT4;
+    g.dy1 = min(g.dy0 + RT4, dh);
+    g.r_lo = yofs[g.dy0] - 1;
+    g.c_lo = xofs[g.dx0] - 1;
+    g.ncol = xofs[min(g.dx0 + 255, dw - 1)] + 2 - g.c_lo + 1;
+    g.nrow = yofs[g.dy1 - 1] + 2 - g.r_lo + 1;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void bgr_to_y_resized_kernel(const uint8_t *__restrict__ bgr, long stride, int sw, int sh,
+                                                               uint8_t *__restrict__ dst, long dstride, int dw, int dh,
+                                                               const int *__restrict__ xofs, const short *__restrict__ alpha,
+                                                               const int *__restrict__ yofs, const short *__restrict__ beta)
+{
+    __shared__ __attribute__((aligned(16))) float hbuf[RMAX4][256];
+    __shared__ uint8_t sbuf[RMAX4][SMAX];
+    const TileGeom g = tile_geom(dw, dh, xofs, yofs);
+    stage_and_hpass(bgr, stride, sw, sh, dw, 0, g, xofs, alpha, sbuf, hbuf);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, dx = g.dx0 + 4 * tx;
+    if (dx >= dw) return;
+    for (int r = 0; r < 8; ++r) {
+        const int dy = g.dy0 + 8 * ty + r;
+        if (dy >= g.dy1) break;
+        const unsigned v = vpass4(hbuf, tx, yofs[dy] - 1 - g.r_lo, beta + 4 * dy, dx, dw);
+        uint8_t *o = dst + (long)dy * dstride + dx;
+        if (dx + 3 < dw) *reinterpret_cast<unsigned *>(o) = v;
+        else
+            for (int c = 0; c < 4 && dx + c < dw; ++c) o[c] = (uint8_t)(v >> (8 * c));
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_merge_kernel(const uint8_t *__restrict__ bgr, long stride, int sw, int sh,
+                                                           const uint8_t *__restrict__ ysr, long ystride,
+                                                           uint8_t *__restrict__ out, long ostride, int dw, int dh,
+                                                           const int *__restrict__ xofs, const short *__restrict__ alpha,
+                                                           const int *__restrict__ yofs, const short *__restrict__ beta)
+{
+    __shared__ __attribute__((aligned(16))) float hbuf[RMAX4][256];
+    __shared__ uint8_t sbuf[RMAX4][SMAX];
+    const TileGeom g = tile_geom(dw, dh, xofs, yofs);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, dx = g.dx0 + 4 * tx;
+    unsigned crcb[2][8];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        if (pl) __syncthreads();            // every thread has finished reading plane 0's sums
+        stage_and_hpass(bgr, stride, sw, sh, dw, 1 + pl, g, xofs, alpha, sbuf, hbuf);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int dy = min(g.dy0 + 8 * ty + r, g.dy1 - 1);
+            crcb[pl][r] = vpass4(hbuf, tx, yofs[dy] - 1 - g.r_lo, beta + 4 * dy, min(dx, dw - 1), dw);
         }
     }
+    if (dx >= dw) return;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int dy = g.dy0 + 8 * ty + r;
+        if (dy >= g.dy1) break;
+        const uint8_t *yrow = ysr + (long)dy * ystride + dx;
+        uint8_t *o = out + (long)dy * ostride + 3L * dx;
+        const bool vec = dx + 3 < dw;
+        unsigned yv = 0;
+        if (vec) yv = *reinterpret_cast<const unsigned *>(yrow);
+        else
+            for (int c = 0; c < 4 && dx + c < dw; ++c) yv |= (unsigned)yrow[c] << (8 * c);
+        uint8_t px[12];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int Y = (yv >> (8 * c)) & 255, Cr = (int)((crcb[0][r] >> (8 * c)) & 255) - 128,
+                      Cb = (int)((crcb[1][r] >> (8 * c)) & 255) - 128;
+            px[3 * c + 0] = sat8(Y + descale14(Cb * 29049));
+            px[3 * c + 1] = sat8(Y + descale14(Cb * -5636 + Cr * -11698));
+            px[3 * c + 2] = sat8(Y + descale14(Cr * 22987));
+        }
+        if (vec) {
+            unsigned *o4 = reinterpret_cast<unsigned *>(o);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                o4[q] = px[4 * q] | (px[4 * q + 1] << 8) | (px[4 * q + 2] << 16) | ((unsigned)px[4 * q + 3] << 24);
+        } else {
+            for (int c = 0; c < 4 && dx + c < dw; ++c)
+                for (int q = 0; q < 3; ++q) o[3 * c + q] = px[3 * c + q];
+        }
+    }
+}
+
+// true when the two fused launches apply (the tiled4 geometry limits, dword-aligned rows)
+bool fused_pipeline_ok(int sw, int sh, int dw, int dh, const void *y_hi, long ystride, const void *out, long ostride)
+{
+    const long cspan = (256L * sw + dw - 1) / dw + 5, span4 = ((long)RT4 * sh + dh - 1) / dh + 4;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(y_hi) | (uintptr_t)ystride | reinterpret_cast<uintptr_t>(out) | (uintptr_t)ostride) & 3) == 0;
+    return span4 <= RMAX4 && cspan <= SMAX && aligned;
+}
+
+hipError_t launch_bgr_to_y_resized(const uint8_t *bgr, long stride, int sw, int sh, uint8_t *dst, long dstride, int dw, int dh,
+                                   const int *xofs, const short *alpha, const int *yofs, const short *beta, hipStream_t st)
+{
+    hipLaunchKernelGGL(bgr_to_y_resized_kernel, dim3((dw + 255) / 256, (dh + RT4 - 1) / RT4), dim3(256), 0, st, bgr, stride, sw,
+                       sh, dst, dstride, dw, dh, xofs, alpha, yofs, beta);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_merge(const uint8_t *bgr, long stride, int sw, int sh, const uint8_t *ysr, long ystride, uint8_t *out,
+                               long ostride, int dw, int dh, const int *xofs, const short *alpha, const int *yofs,
+                               const short *beta, hipStream_t st)
+{
+    hipLaunchKernelGGL(resize_merge_kernel, dim3((dw + 255) / 256, (dh + RT4 - 1) / RT4), dim3(256), 0, st, bgr, stride, sw, sh,
+                       ysr, ystride, out, ostride, dw, dh, xofs, alpha, yofs, beta);
+    return hipGetLastError();
 }
 
 hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,

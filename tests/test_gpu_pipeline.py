@@ -52,7 +52,10 @@ def test_resize_cubic_bit_exact(gpu_ctx, sw, sh, dw, dh):
     assert np.array_equal(gpu_ctx.resize_cubic(smooth, dw, dh), oracle.resize_cubic(smooth, dw, dh))
 
 
-@pytest.mark.parametrize("w,h,scale", [(40, 30, 2.0), (97, 61, 1.5), (33, 20, 3.0), (64, 48, 1.3)])
+# (output widths that are multiples of four take the two fused launches around the conv path -- colour conversion inside the
+# resize kernels -- the others the three separate kernels: both forms are covered)
+@pytest.mark.parametrize("w,h,scale", [(40, 30, 2.0), (97, 61, 1.5), (33, 20, 3.0), (64, 48, 1.3), (320, 180, 2.0),
+                                       (200, 100, 2.4), (130, 70, 4.0)])
 def test_whole_pipeline(gpu_ctx, weights_blob, w, h, scale):
     bgr = synth_bgr(w, h)
     assert S.scaled_size(w, h, scale) == oracle.scaled_size(w, h, scale)
