@@ -382,7 +382,11 @@ Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, 
     return best;
 }
 
-bool bad_plane(const void *p, size_t stride, int w, int h) { return !p || w <= 0 || h <= 0 || stride < (size_t)w; }
+// (row strides stay below 2^30 elements: the kernels add a lane's column to one row stride in 32 bits)
+bool bad_plane(const void *p, size_t stride, int w, int h)
+{
+    return !p || w <= 0 || h <= 0 || stride < (size_t)w || stride >= ((size_t)1 << 30);
+}
 // the kernels address a lane's plane element with a 32-bit offset from a per-plane scalar base
 bool bad_pitch(size_t plane_pitch) { return plane_pitch >= ((size_t)1 << 29); }
 
