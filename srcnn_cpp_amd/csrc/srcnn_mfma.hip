@@ -50,12 +50,14 @@
 // 3840x2160 plane, written and read once); the kernel is bound by the f32 MFMA pipe
 // (130 MFMA x 64 cycles per 32 pixels per SIMD).
 //
-// LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + F tiles 2x3x6x128 f32
-// (18 KiB) = 35 KiB; 236 VGPRs -> two workgroups per CU, i.e. two waves per
+// LDS per workgroup: Y ring 2x16x136 f32 (17.0 KiB) + F tiles (18 KiB; the production kernel uses a ring of four rows
+// of 6x128 f32 in it) = 35 KiB; 249 VGPRs -> two workgroups per CU, i.e. two waves per
 // SIMD: while one wave waits (LDS, barrier, a dependent chain's result) the other keeps the matrix
 // pipe busy.  Vector instructions are NOT hidden that way (profiles/r02/ablation.txt): every one
-// inside the MFMA streams costs matrix-pipe time, so the row loop keeps them few -- ReLU packed,
-// bias as accumulator init, row addresses in scalar registers, stores exec-masked.
+// costs ~6 cycles of matrix-pipe time wherever it sits, so the row loop keeps them few -- ReLU packed,
+// bias as accumulator init, row addresses in scalar registers (saddr form), stores exec-masked, and a FAST row body
+// (see the row loop) that is unrolled over four rows and finishes two output rows at once on the two lane halves:
+// 51 vector instructions per wave-row next to the 130 MFMAs.
 // MODE_L3 (HBM-bound) needs only the F tiles and runs four workgroups per CU.
 #include "srcnn_kernels.h"
 
