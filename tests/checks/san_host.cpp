@@ -26,6 +26,9 @@ hipError_t launch_conv55_exact(const float *, long, long, long, uint8_t *, float
 hipError_t launch_bgr2ycrcb(const uint8_t *, long, int, int, uint8_t *, long, long, hipStream_t) { return never(); }
 hipError_t launch_ycrcb2bgr(const uint8_t *, long, const uint8_t *, long, long, int, int, uint8_t *, long, hipStream_t) { return never(); }
 hipError_t launch_resize_cubic(const uint8_t *, long, long, int, int, uint8_t *, long, long, int, int, int, const int *, const short *, const int *, const short *, hipStream_t) { return never(); }
+bool fused_pipeline_ok(int, int, int, int, const void *, long, const void *, long) { return false; }
+hipError_t launch_bgr_to_y_resized(const uint8_t *, long, int, int, uint8_t *, long, int, int, const int *, const short *, const int *, const short *, hipStream_t) { return never(); }
+hipError_t launch_resize_merge(const uint8_t *, long, int, int, const uint8_t *, long, uint8_t *, long, int, int, const int *, const short *, const int *, const short *, hipStream_t) { return never(); }
 }  // namespace srcnn
 
 extern "C" {
