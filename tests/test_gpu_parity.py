@@ -296,6 +296,33 @@ def test_row_stripes_equal_whole_image(gpu_ctx, weights_blob, n_stripes):
     assert np.array_equal(out, whole)
 
 
+@pytest.mark.parametrize("w,h", [(300, 97), (3840, 601)])
+def test_row_ranges_of_every_alignment(gpu_ctx, weights_blob, w, h):
+    """The steady-state rows of a work item run through a row body that is unrolled over four rows and finishes two
+    output rows at once (csrc/srcnn_mfma.hip, FAST body); the rows before the first and behind the last multiple of
+    four, the image's first and last rows and the rows next to a seam or a stripe edge go through the general body.
+    Every alignment of a row range against that period -- first row 0..9, last row H-9..H, short and tall ranges, padded
+    output rows -- must give the bytes of the whole-image model.  300x97 runs on the regular grid (short segments,
+    general body only), 3840x601 as work items of ~35 rows with seams (FAST body in the middle of every item)."""
+    torch = _torch()
+    y = synth_luma(w, h, frame=21)
+    model, _ = oracle.gpuorder_forward_y(y, weights_blob)
+    assert np.array_equal(gpu_ctx.forward_y(y), model)
+    d_in = torch.from_numpy(y).cuda()
+    ranges = [(r0, r1) for r0 in range(0, 10) for r1 in (h, h - 1, h - 2, h - 3, h - 5, h - 9)]
+    ranges += [(r0, r0 + n) for r0 in (0, 3, 14, 41) for n in (1, 2, 5, 11, 12, 13, 19, 24, 31)]
+    if h > 400:
+        ranges += [(r0, r0 + n) for r0 in (7, 100, 233) for n in (200, 257, 300, 366)]
+    for r0, r1 in ranges:
+        d_out = torch.full((r1 - r0, w + 12), 5, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu_ctx.forward_y_rows_dev(d_in.data_ptr(), w, 0, d_out.data_ptr(), w + 12, r0, w, h, r0, r1)
+        gpu_ctx.synchronize()
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got[:, :w], model[r0:r1]), (r0, r1)
+        assert (got[:, w:] == 5).all(), (r0, r1)    # nothing written beyond the row
+
+
 @pytest.mark.parametrize("w,h", [(3840, 2160), (1920, 1080), (2000, 1203), (992, 1700), (7680, 4320), (125, 6400)])
 def test_single_plane_work_items_equal_batch_grid(gpu_ctx, weights_blob, w, h):
     """Launch-geometry independence at full sizes: a plane launched alone is cut into
