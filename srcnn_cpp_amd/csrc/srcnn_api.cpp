@@ -66,6 +66,8 @@ struct srcnn_ctx {
         int count = 0;                  // 0: this geometry uses the regular grid
         int n_seams = 0;
         DevBuf dev, dev_seams;
+        DevBuf dev_winmap;              // [n_strips][rows] bytes: 1 = the row lies in a seam window of that strip (separated plans)
+        bool separated = false;         // seam windows of neighbouring strips share no row: one seam launch (plan_items_balanced())
         unsigned long stamp = 0;        // last use, for eviction
     };
     static constexpr int kItemTables = 8;
@@ -403,6 +405,7 @@ bool bad_pitch(size_t plane_pitch) { return plane_pitch >= ((size_t)1 << 29); }
 // geometry does not qualify (the regular grid is used instead).
 struct ItemPlan {
     std::vector<int> items, seams;
+    bool separated = false;        // no two seams of neighbouring strips closer than SEAM_ROWS rows (plan_items_balanced())
     int count() const { return (int)items.size() / ITEM_INTS; }
     int n_seams() const { return (int)seams.size() / 2; }
 };
@@ -474,6 +477,19 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
             items.push_back({s, upto - used, -1, fast});
             used = upto;
         }
+        // Strips get the same item heights, so their boundaries would line up from strip to strip.  Every second strip
+        // is shifted up by kStagger rows (its first item shorter, its last one taller): the seam windows of neighbouring
+        // strips then lie well apart (ItemPlan::separated: one seam launch instead of two) and the search below can
+        // still move boundaries by a few rows.
+        constexpr int kStagger = 16;
+        if ((s & 1) && k[(size_t)s] >= 3) {
+            Item &first = items[items.size() - (size_t)k[(size_t)s]], &last = items.back();
+            const int x = std::min(kStagger, first.rows - kMinRows);
+            if (x > 0) {
+                first.rows -= x;
+                last.rows += x;
+            }
+        }
     }
     // the alternation above may not hand out exactly na fast items per strip when na != nb: recount and fix the flags
     for (int s = 0; s < n_strips; ++s) {
@@ -498,41 +514,163 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
     std::vector<double> fin((size_t)n_cu);
     for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
     std::vector<int> by_time((size_t)n_cu);
-    for (int iter = 0; iter < 40 * n_cu; ++iter) {
-        for (int c = 0; c < n_cu; ++c) by_time[(size_t)c] = c;
-        std::sort(by_time.begin(), by_time.end(), [&](int x, int y) { return fin[(size_t)x] > fin[(size_t)y]; });
-        bool moved = false;
-        for (int rank = 0; rank < n_cu && !moved; ++rank) {
-            const int c = by_time[(size_t)rank];
-            double best_gain = 1e-6;
-            int best_from = -1, best_to = -1;
-            for (int from : {fi[(size_t)c], si[(size_t)c]}) {
-                if (items[(size_t)from].rows <= kMinRows) continue;
-                items[(size_t)from].rows -= 1;
-                const double mine = finish(c);
-                for (int to : in_strip[(size_t)items[(size_t)from].strip]) {
-                    const int c2 = items[(size_t)to].cu;
-                    if (c2 == c) continue;
-                    items[(size_t)to].rows += 1;
-                    const double theirs = finish(c2);
-                    const double gain = fin[(size_t)c] - std::max(mine, theirs);
-                    if (theirs < fin[(size_t)c] && gain > best_gain) { best_gain = gain; best_from = from; best_to = to; }
-                    items[(size_t)to].rows -= 1;
-                }
-                items[(size_t)from].rows += 1;
-            }
-            if (best_from >= 0) {
-                items[(size_t)best_from].rows -= 1;
-                items[(size_t)best_to].rows += 1;
-                fin[(size_t)c] = finish(c);
-                fin[(size_t)items[(size_t)best_to].cu] = finish(items[(size_t)best_to].cu);
-                moved = true;
-            }
+    // Seam windows: the boundary rows of strip s (relative to row_begin) and whether they keep SEAM_ROWS rows away from
+    // every boundary of the strips next to it (ItemPlan::separated: one seam launch instead of two).
+    auto bounds = [&](int s_) {
+        std::vector<int> b;
+        int y = 0;
+        for (size_t q = 0; q + 1 < in_strip[(size_t)s_].size(); ++q) b.push_back(y += items[(size_t)in_strip[(size_t)s_][q]].rows);
+        return b;
+    };
+    auto apart = [&](const std::vector<int> &x, const std::vector<int> &y) {
+        for (int u : x)
+            for (int v : y)
+                if (std::abs(u - v) < SEAM_ROWS) return false;
+        return true;
+    };
+    auto strip_apart = [&](int s_) {
+        const std::vector<int> b = bounds(s_);
+        return (s_ == 0 || apart(b, bounds(s_ - 1))) && (s_ + 1 >= n_strips || apart(b, bounds(s_ + 1)));
+    };
+    // local search: take one row from an item of the slowest improvable CU, give it to the item of the same strip
+    // whose CU stays fastest; stop when no such move lowers the pair's maximum.  `keep_apart`: only moves that leave the
+    // strip's seam windows clear of its neighbours'.
+    // the same test for ONE candidate move of the search, incrementally: a row from item `from` to item `to` of a strip
+    // shifts the boundaries between them by one row (cur[s] = the strip's boundaries, kept in step by move_apply())
+    std::vector<std::vector<int>> cur((size_t)n_strips);
+    std::vector<int> pos(items.size());
+    for (int s_ = 0; s_ < n_strips; ++s_)
+        for (size_t q = 0; q < in_strip[(size_t)s_].size(); ++q) pos[(size_t)in_strip[(size_t)s_][q]] = (int)q;
+    auto clear_of = [&](const std::vector<int> &nbr, int b) {       // b keeps SEAM_ROWS rows away from every entry of nbr (sorted)
+        const auto it = std::lower_bound(nbr.begin(), nbr.end(), b);
+        return (it == nbr.end() || *it - b >= SEAM_ROWS) && (it == nbr.begin() || b - *(it - 1) >= SEAM_ROWS);
+    };
+    auto move_ok = [&](int from, int to) {
+        const int s_ = items[(size_t)from].strip, pa = pos[(size_t)from], pb = pos[(size_t)to];
+        const int lo = std::min(pa, pb), hi = std::max(pa, pb) - 1, delta = pa < pb ? -1 : 1;
+        for (int q = lo; q <= hi; ++q) {
+            const int b = cur[(size_t)s_][(size_t)q] + delta;
+            if (s_ > 0 && !clear_of(cur[(size_t)s_ - 1], b)) return false;
+            if (s_ + 1 < n_strips && !clear_of(cur[(size_t)s_ + 1], b)) return false;
         }
-        if (!moved) break;
+        return true;
+    };
+    auto move_apply = [&](int from, int to) {
+        const int s_ = items[(size_t)from].strip, pa = pos[(size_t)from], pb = pos[(size_t)to];
+        const int lo = std::min(pa, pb), hi = std::max(pa, pb) - 1, delta = pa < pb ? -1 : 1;
+        for (int q = lo; q <= hi; ++q) cur[(size_t)s_][(size_t)q] += delta;
+    };
+    auto search = [&](bool keep_apart) {
+        for (int iter = 0; iter < 40 * n_cu; ++iter) {
+            for (int c = 0; c < n_cu; ++c) by_time[(size_t)c] = c;
+            std::sort(by_time.begin(), by_time.end(), [&](int x, int y) { return fin[(size_t)x] > fin[(size_t)y]; });
+            bool moved = false;
+            for (int rank = 0; rank < n_cu && !moved; ++rank) {
+                const int c = by_time[(size_t)rank];
+                double best_gain = 1e-6;
+                int best_from = -1, best_to = -1;
+                for (int from : {fi[(size_t)c], si[(size_t)c]}) {
+                    if (items[(size_t)from].rows <= kMinRows) continue;
+                    items[(size_t)from].rows -= 1;
+                    const double mine = finish(c);
+                    for (int to : in_strip[(size_t)items[(size_t)from].strip]) {
+                        const int c2 = items[(size_t)to].cu;
+                        if (c2 == c) continue;
+                        items[(size_t)to].rows += 1;
+                        const double theirs = finish(c2);
+                        const double gain = fin[(size_t)c] - std::max(mine, theirs);
+                        if (theirs < fin[(size_t)c] && gain > best_gain && (!keep_apart || move_ok(from, to))) {
+                            best_gain = gain;
+                            best_from = from;
+                            best_to = to;
+                        }
+                        items[(size_t)to].rows -= 1;
+                    }
+                    items[(size_t)from].rows += 1;
+                }
+                if (best_from >= 0) {
+                    if (keep_apart) move_apply(best_from, best_to);
+                    items[(size_t)best_from].rows -= 1;
+                    items[(size_t)best_to].rows += 1;
+                    fin[(size_t)c] = finish(c);
+                    fin[(size_t)items[(size_t)best_to].cu] = finish(items[(size_t)best_to].cu);
+                    moved = true;
+                }
+            }
+            if (!moved) break;
+        }
+    };
+    // move colliding boundaries apart first (left to right: the shift that clears the left neighbour's windows with some
+    // slack and keeps the two CUs involved fastest), then balance under that constraint; if that fails, balance freely
+    // (two seam launches then)
+    const std::vector<Item> start = items;
+    static const char *env_sep = std::getenv("SRCNN_DEBUG_SEPARATE");     // experiment knob: 0 = never keep the seam windows apart
+    // (worth trying only with neighbours to keep apart from and items tall enough to give up a few rows)
+    bool separated = !(env_sep && std::atoi(env_sep) == 0) && n_strips >= 2 && hs / (kbase + 1) >= 24;
+    constexpr int kSlack = 4;        // preferred extra distance: the search needs room to move boundaries
+    for (int s_ = 1; s_ < n_strips && separated; ++s_) {
+        const std::vector<int> left = bounds(s_ - 1);
+        const std::vector<int> &mine = in_strip[(size_t)s_];
+        for (size_t q = 0; q + 1 < mine.size() && separated; ++q) {
+            int y = 0;
+            for (size_t r = 0; r <= q; ++r) y += items[(size_t)mine[r]].rows;
+            auto dist = [&](int b) {
+                int dmin = 1 << 30;
+                for (int v : left) dmin = std::min(dmin, std::abs(v - b));
+                return dmin;
+            };
+            if (dist(y) >= SEAM_ROWS + kSlack) continue;
+            Item &up = items[(size_t)mine[q]], &dn = items[(size_t)mine[q + 1]];
+            int best_d = 0;
+            double best_t = 1e30;
+            for (int d = -3 * SEAM_ROWS; d <= 3 * SEAM_ROWS; ++d) {
+                if (dist(y + d) < SEAM_ROWS || up.rows + d < kMinRows || dn.rows - d < kMinRows) continue;
+                up.rows += d;
+                dn.rows -= d;
+                const double t = std::max(finish(up.cu), finish(dn.cu)) + 0.5 * std::abs(d) +
+                                 4.0 * std::max(0, SEAM_ROWS + kSlack - dist(y + d));
+                up.rows -= d;
+                dn.rows += d;
+                if (t < best_t) { best_t = t; best_d = d; }
+            }
+            if (best_t >= 1e30) { separated = false; break; }
+            up.rows += best_d;
+            dn.rows -= best_d;
+        }
+    }
+    for (int s_ = 0; s_ < n_strips && separated; ++s_) separated = strip_apart(s_);
+    auto slowest = [&] {
+        double mx = 0.0;
+        for (int c = 0; c < n_cu; ++c) mx = std::max(mx, fin[(size_t)c]);
+        return mx;
+    };
+    if (separated) {
+        for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
+        for (int s_ = 0; s_ < n_strips; ++s_) cur[(size_t)s_] = bounds(s_);
+        search(true);
+    }
+    // the unconstrained plan, for comparison: keeping the windows apart must not cost more than the launch it saves
+    // (short items -- 14 rows at 1280x720 -- cannot afford boundaries moved by four rows)
+    const std::vector<Item> apart_items = items;
+    const double apart_t = separated ? slowest() : 1e30;
+    items = start;
+    for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
+    search(false);
+    constexpr double kLaunchSaved = 2.0;      // us, conservative
+    if (separated && apart_t <= slowest() + kLaunchSaved) {
+        items = apart_items;
+        for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
+    } else {
+        separated = false;
+    }
+    if (std::getenv("SRCNN_DEBUG_PLANLOG")) {
+        double mx = 0, mn = 1e30;
+        for (int c = 0; c < n_cu; ++c) { mx = std::max(mx, fin[(size_t)c]); mn = std::min(mn, fin[(size_t)c]); }
+        std::fprintf(stderr, "plan: separated=%d finish %.1f..%.1f\n", (int)separated, mn, mx);
     }
     // positions: the items of a strip in creation order; seams between neighbours
     ItemPlan plan;
+    plan.separated = separated;
     std::vector<int> y0(items.size()), up(items.size(), -1), dn(items.size(), -1);
     for (int s = 0; s < n_strips; ++s) {
         int y = row_begin, prev = -1;
@@ -558,8 +696,8 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
     return plan;
 }
 
-ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
-                    bool want_seams = false)
+ItemPlan plan_items_raw(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
+                        bool want_seams = false)
 {
     const ItemPlan none;
     static const char *env_plan = std::getenv("SRCNN_DEBUG_PLAN");      // experiment knob: 1 = the round-1 planner
@@ -642,15 +780,20 @@ int skew_percent()
     return env_skew ? std::atoi(env_skew) : 10;
 }
 
+// A seam's WINDOW is the four output rows b-2 .. b+1 around its boundary row b, which the seam kernel finishes.  When no
+// window of a strip shares a row with a window of a NEIGHBOURING strip, the block that finishes a seam can also finish the
+// four column-seam pixels either side of its strip on those rows -- the neighbour's values there are complete exports of the
+// strip kernel -- and the row-seam and column-seam kernels no longer depend on each other: one launch instead of two.
+// The balanced planner builds such plans (ItemPlan::separated) where that costs no balance; other plans keep two launches.
+ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
+                    bool want_seams = false)
+{
+    return plan_items_raw(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams);
+}
+
 // Device copy of plan_items() for this geometry, from the context's table cache.  *n_items = 0: use the
 // regular grid.  A table is written once, before its first use, into memory no earlier launch reads
 // (a fresh slot, or an evicted one after its last reader has finished), and never modified afterwards.
-bool balanced_plan_wanted(int wgs_per_cu, bool want_seams, int skew_pct)
-{
-    static const char *env_plan = std::getenv("SRCNN_DEBUG_PLAN");      // experiment knob: 1 = the round-1 planner
-    return wgs_per_cu == 2 && want_seams && skew_pct > 0 && !(env_plan && std::atoi(env_plan) == 1);
-}
-
 int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
                 const srcnn_ctx::ItemTable **table)
 {
@@ -665,13 +808,7 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
         }
         if (t.stamp < victim->stamp) victim = &t;
     }
-    ItemPlan plan;
-    bool balanced = false;
-    if (balanced_plan_wanted(wgs_per_cu, want_seams, key[3])) {
-        plan = plan_items_balanced(c->n_cu, n_strips, row_begin, row_end, key[3]);
-        balanced = plan.count() > 0;
-    }
-    if (!balanced) plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
+    const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
     if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());              // evicting: its readers must be done
     if (plan.count() > 0) {
         int rc;
@@ -681,11 +818,23 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
             if ((rc = reserve(c, victim->dev_seams, plan.seams.size() * sizeof(int)))) return rc;
             HIP_TRY(c, hipMemcpy(victim->dev_seams.p, plan.seams.data(), plan.seams.size() * sizeof(int),
                                  hipMemcpyHostToDevice));
+            if (plan.separated) {
+                const int rows = row_end - row_begin;
+                std::vector<unsigned char> win((size_t)n_strips * rows, 0);
+                for (int id = 0; id < plan.n_seams(); ++id) {
+                    const int s_ = plan.seams[2 * (size_t)id], b = plan.seams[2 * (size_t)id + 1];
+                    for (int y = b - 2; y < b + 2; ++y)
+                        if (y >= row_begin && y < row_end) win[(size_t)s_ * rows + (y - row_begin)] = 1;
+                }
+                if ((rc = reserve(c, victim->dev_winmap, win.size()))) return rc;
+                HIP_TRY(c, hipMemcpy(victim->dev_winmap.p, win.data(), win.size(), hipMemcpyHostToDevice));
+            }
         }
     }
     std::memcpy(victim->key, key, sizeof(key));
     victim->count = plan.count();
     victim->n_seams = plan.n_seams();
+    victim->separated = plan.n_seams() > 0 && plan.separated;
     victim->stamp = ++c->item_clock;
     *table = victim;
     return SRCNN_OK;
@@ -880,6 +1029,15 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
     if (p.tune & 32) return SRCNN_OK;          // timing experiment: strip kernel only (wrong pixels next to the seams)
+    // Row seams and column seams in ONE launch when the plan keeps the seam windows of neighbouring strips apart
+    // (plan_items_balanced()): the blocks that finish a row seam then also finish the column-seam pixels of their four
+    // rows, the column-seam blocks skip those rows, and neither waits for the other.
+    static const char *env_merge = std::getenv("SRCNN_DEBUG_SEAM_MERGE");      // experiment knob: 0 = two launches
+    if (p.seam && p.cseam && table->separated && !(env_merge && std::atoi(env_merge) == 0)) {
+        HIP_TRY(c, launch_seams_merged(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p),
+                                       static_cast<const unsigned char *>(table->dev_winmap.p), n_frames, c->stream));
+        return SRCNN_OK;
+    }
     if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p), c->stream));
     if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     return SRCNN_OK;
@@ -1129,6 +1287,7 @@ void srcnn_destroy(srcnn_ctx *c)
     for (auto &t : c->item_tables) {
         release(t.dev);
         release(t.dev_seams);
+        release(t.dev_winmap);
     }
     for (int k = 0; k < 2; ++k) {
         release(c->lane_in[k]);

@@ -810,19 +810,51 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 // would have contributed to the upper item's chains (same adds in the same order as vertical() / hp_use() of
 // srcnn_strip_kernel), then the horizontal 5-term sum, bias, truncate, clamp (src/srcnn.cpp:235-240).
 // One workgroup per seam, thread <-> (wave, lane) as in the strip kernel.
+// Export slot e of a finished F-tile row (planes at tile[n * FW + c]) as cseam_export() computes it: the same terms in the same order.
+__device__ __forceinline__ float cseam_value(const float *tile, int e)
+{
+    const signed char *t = CSEAM_TERMS[e];
+    float v = tile[t[1] * FW + t[2]];
+    for (int i = 1; i < t[0]; ++i) v += tile[t[1 + 2 * i] * FW + t[2 + 2 * i]];
+    return v;
+}
+
+// The four pixels around a strip boundary from the left strip's exports es[0..4] and the right strip's et[5..14]
+// (srcnn_cseam_kernel's arithmetic, shared with the merged form of the seam kernel).
 template <bool PRE>
-__global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams p, const int *__restrict__ seams)
+__device__ __forceinline__ void cseam_pixels(const StripParams &p, const float *es, const float *et, int frame, int y, int xt)
+{
+    float acc[4];
+    acc[0] = es[0] + et[13];
+    acc[1] = (es[1] + et[12]) + et[14];
+    acc[2] = (((es[2] + es[4]) + et[5]) + et[6]) + et[7];
+    acc[3] = (((es[3] + et[8]) + et[9]) + et[10]) + et[11];
+    const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + xt - 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (xt - 2 + k >= p.width) break;
+        const float val = acc[k] + p.b3;
+        p.dst[o + k] = (uint8_t)clampi((int)val, 0, 255);
+        if constexpr (PRE) p.pre[o + k] = val;
+    }
+}
+
+// MERGED: the plan keeps the seam windows of neighbouring strips apart, so this block also finishes the column-seam pixels
+// either side of its strip on its four rows (the neighbours' values there are complete exports of the strip kernel) and
+// exports nothing itself.
+template <bool PRE, bool MERGED>
+__device__ __forceinline__ void seam_block(const StripParams &p, const int *__restrict__ seams, int blk)
 {
     __shared__ float ft[SEAM_ROWS][6][FW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, half = lane >> 5;
     constexpr int HALO = 2;
-    const int frame = blockIdx.x / p.seams_per_frame, sid = blockIdx.x - frame * p.seams_per_frame;
+    const int frame = blk / p.seams_per_frame, sid = blk - frame * p.seams_per_frame;
     const int strip = seams[2 * sid], b = seams[2 * sid + 1];
     const int W = p.width;
     const bool cs = p.cseam != nullptr;
     const int halo_c = cs ? 0 : HALO;
     const int gx0 = strip * (FW - 2 * halo_c) - halo_c, xi = 32 * wave + j, gx = gx0 + xi;
-    const float *sc = p.seam + (long)blockIdx.x * SEAM_FLOATS * NTHREADS + tid;
+    const float *sc = p.seam + (long)blk * SEAM_FLOATS * NTHREADS + tid;
     float R[4][3];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -845,7 +877,27 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
         }
     }
     __syncthreads();
-    if (cs && wave == 0) {
+    if constexpr (MERGED) {
+        // threads 0..7: (side, row) -- side 0 = the boundary with the left neighbour, side 1 = with the right one
+        if (tid < 2 * SEAM_ROWS) {
+            const int side = tid / SEAM_ROWS, r = tid % SEAM_ROWS, y = b - 2 + r;
+            const int rows = p.row_end - p.row_begin;
+            const int nb = side ? strip + 1 : strip - 1;
+            if (nb >= 0 && nb < p.strips_total && y >= p.row_begin && y < p.row_end) {
+                const float *theirs = p.cseam + (((long)frame * p.strips_total + nb) * rows + (y - p.row_begin)) * CSEAM_FLOATS;
+                float mine[15];
+                if (side) {
+#pragma unroll
+                    for (int e = 0; e < 5; ++e) mine[e] = cseam_value(&ft[r][0][0], e);
+                    cseam_pixels<PRE>(p, mine, theirs, frame, y, (strip + 1) * FW);
+                } else {
+#pragma unroll
+                    for (int e = 5; e < 15; ++e) mine[e] = cseam_value(&ft[r][0][0], e);
+                    cseam_pixels<PRE>(p, theirs, mine, frame, y, strip * FW);
+                }
+            }
+        }
+    } else if (cs && wave == 0) {
         const CseamLane cl = cseam_lane(lane);
         for (int r = 0; r < SEAM_ROWS; ++r)
             cseam_export(&ft[r][0][0], p.cseam + (((long)frame * p.strips_total + strip) * (p.row_end - p.row_begin) + (b - 2 + r - p.row_begin)) * CSEAM_FLOATS, lane, cl);
@@ -868,31 +920,47 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams 
     }
 }
 
+template <bool PRE>
+__global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams p, const int *__restrict__ seams)
+{
+    seam_block<PRE, false>(p, seams, (int)blockIdx.x);
+}
+
 // The four output pixels around every strip boundary, every row of the launch: columns xT-2, xT-1 of the left
 // strip S (its pixels 126, 127) and xT, xT+1 of the right strip T (its pixels 0, 1), from the two strips' exports
 // (CSEAM_TERMS), added in the order of hp_use(): F0 + F1 + F2 + F3 + F4, then the bias, truncate, clamp.
+// `winmap` (merged launch only): rows inside a seam window of either strip belong to that seam's block.
+template <bool PRE>
+__device__ __forceinline__ void cseam_block(const StripParams &p, long blk_in_frame, int frame, const unsigned char *__restrict__ winmap)
+{
+    const int rows = p.row_end - p.row_begin;
+    const long idx = blk_in_frame * 256 + threadIdx.x;
+    const int v = (int)(idx / rows), yrel = (int)(idx - (long)v * rows);
+    if (v >= p.strips_total - 1) return;
+    if (winmap && (winmap[(long)v * rows + yrel] | winmap[(long)(v + 1) * rows + yrel])) return;
+    const float *es = p.cseam + (((long)frame * p.strips_total + v) * rows + yrel) * CSEAM_FLOATS;
+    const float *et = es + (long)rows * CSEAM_FLOATS;
+    cseam_pixels<PRE>(p, es, et, frame, p.row_begin + yrel, (v + 1) * FW);
+}
+
 template <bool PRE>
 __global__ __launch_bounds__(256) void srcnn_cseam_kernel(const StripParams p)
 {
-    const int rows = p.row_end - p.row_begin, frame = blockIdx.y;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int v = (int)(idx / rows), yrel = (int)(idx - (long)v * rows);
-    if (v >= p.strips_total - 1) return;
-    const float *es = p.cseam + (((long)frame * p.strips_total + v) * rows + yrel) * CSEAM_FLOATS;
-    const float *et = es + (long)rows * CSEAM_FLOATS;
-    const int xt = (v + 1) * FW;
-    float acc[4];
-    acc[0] = es[0] + et[13];
-    acc[1] = (es[1] + et[12]) + et[14];
-    acc[2] = (((es[2] + es[4]) + et[5]) + et[6]) + et[7];
-    acc[3] = (((es[3] + et[8]) + et[9]) + et[10]) + et[11];
-    const long o = (long)frame * p.dst_frame_pitch + (long)(p.row_begin + yrel - p.dst_row0) * p.dst_stride + xt - 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (xt - 2 + k >= p.width) break;
-        const float val = acc[k] + p.b3;
-        p.dst[o + k] = (uint8_t)clampi((int)val, 0, 255);
-        if constexpr (PRE) p.pre[o + k] = val;
+    cseam_block<PRE>(p, (long)blockIdx.x, (int)blockIdx.y, nullptr);
+}
+
+// Row seams and column seams in one launch: blocks [0, n_seams) finish the row seams (and the column-seam pixels of their
+// rows), the others the column seams of all remaining rows; no block depends on another.
+template <bool PRE>
+__global__ __launch_bounds__(NTHREADS) void srcnn_seams_merged_kernel(const StripParams p, const int *__restrict__ seams, int n_seams,
+                                                                     const unsigned char *__restrict__ winmap, int cblocks_per_frame)
+{
+    static_assert(NTHREADS == 256, "both roles use 256 threads");
+    if ((int)blockIdx.x < n_seams) {
+        seam_block<PRE, true>(p, seams, (int)blockIdx.x);
+    } else {
+        const int q = (int)blockIdx.x - n_seams;
+        cseam_block<PRE>(p, (long)(q % cblocks_per_frame), q / cblocks_per_frame, winmap);
     }
 }
 
@@ -903,6 +971,17 @@ hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_frames);
     if (p.pre) hipLaunchKernelGGL((srcnn_cseam_kernel<true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((srcnn_cseam_kernel<false>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_seams_merged(const StripParams &p, int n_seams /* of all frames */, const int *d_seams, const unsigned char *d_winmap,
+                               int n_frames, hipStream_t stream)
+{
+    const long n = (long)(p.strips_total - 1) * (p.row_end - p.row_begin);
+    const int cb = (int)((n + 255) / 256);
+    const dim3 grid((unsigned)(n_seams + cb * n_frames));
+    if (p.pre) hipLaunchKernelGGL((srcnn_seams_merged_kernel<true>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
+    else hipLaunchKernelGGL((srcnn_seams_merged_kernel<false>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@ size_t strip_lds_bytes(int) { return 35840; }
 size_t split16_lds_bytes() { return 0; }
 hipError_t launch_seams(const StripParams &, int, const int *, hipStream_t) { return never(); }
 hipError_t launch_cseams(const StripParams &, int, hipStream_t) { return never(); }
+hipError_t launch_seams_merged(const StripParams &, int, const int *, const unsigned char *, int, hipStream_t) { return never(); }
 hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }

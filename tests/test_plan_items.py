@@ -93,7 +93,9 @@ def test_fast_and_slow_items_pair_up_per_cu():
         assert len(it) == 512
         h = it[:, 2] - it[:, 1]
         per_cu = h[:256] + h[256:]
-        assert per_cu.max() - per_cu.min() <= max(4, 0.025 * per_cu.mean())
+        # (3 %: every second strip is shifted by 16 rows so that the seam windows of neighbouring strips stay apart -- one seam
+        # launch instead of two -- which costs a single CU a few rows; the estimated finish times below are what counts)
+        assert per_cu.max() - per_cu.min() <= max(5, 0.03 * per_cu.mean())
         fin = np.array([finish_estimate(f, s) for f, s in zip(h[:256], h[256:])])
         assert fin.max() <= 1.005 * np.median(fin) + 4.3          # within one row of the median CU
         assert h[:256].mean() > 1.1 * h[256:].mean()          # first-dispatched blocks are the taller ones
