@@ -13,9 +13,10 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
-# kernels of one step: the strip kernel does the work; with seams (float32 mode) two small kernels finish the
-# rows / columns at item and strip boundaries -- their HBM bytes belong to the step's traffic
-KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seam_kernel", "srcnn_cseam_kernel"], "split16": ["srcnn_split16_kernel"]}
+# kernels of one step: the strip kernel does the work; with seams (float32 mode) one small launch (srcnn_seams_merged_kernel;
+# two launches, srcnn_seam_kernel + srcnn_cseam_kernel, for plans whose seam windows are not kept apart) finishes the rows /
+# columns at item and strip boundaries -- their HBM bytes belong to the step's traffic
+KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seams_merged_kernel", "srcnn_seam_kernel", "srcnn_cseam_kernel"], "split16": ["srcnn_split16_kernel"]}
 traffic_rec = {}
 for mode, knames in KERNEL.items():
     kname = knames[0]
