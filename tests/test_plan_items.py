@@ -100,3 +100,20 @@ def test_fast_and_slow_items_pair_up_per_cu():
         assert fin.max() <= 1.005 * np.median(fin) + 4.3          # within one row of the median CU
         assert h[:256].mean() > 1.1 * h[256:].mean()          # first-dispatched blocks are the taller ones
         assert (h >= 10).all()
+
+
+def test_seam_windows_of_neighbouring_strips_stay_apart():
+    """One seam launch instead of two (srcnn_seams_merged_kernel) rests on this: the four-row windows around the seams of
+    NEIGHBOURING strips share no row, so the block that finishes a row seam can take the neighbours' column-seam values of
+    those rows from the strip kernel's exports.  The balanced planner guarantees it for the geometries it marks separated;
+    the full-size ones must be among them (and keep their balance: test_fast_and_slow_items_pair_up_per_cu)."""
+    for (n_strips, rows) in [(30, 2160), (60, 4320), (15, 1080), (45, 3240), (31, 2160), (30, 1080)]:
+        it, se = plan(256, n_strips, 0, rows)
+        assert len(it) == 512 and len(se) > 0
+        for s in range(1, n_strips):
+            a, b = se[se[:, 0] == s - 1][:, 1], se[se[:, 0] == s][:, 1]
+            if len(a) and len(b):
+                assert np.abs(a[:, None] - b[None, :]).min() >= 4, (n_strips, rows, s)
+        for s in range(n_strips):                      # ... and inside a strip two seams are at least an item apart
+            b = np.sort(se[se[:, 0] == s][:, 1])
+            assert (np.diff(b) >= 10).all()
