@@ -537,7 +537,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         const unsigned lo = lane_off(pl_lane * 4u);       // BYTE offset, 32 bits (host: pl_pitch < 2^29)
 #pragma unroll
         for (int r = 0; r < 16; ++r)                      // scalar base per plane pair
-            d2n[r] = *(const __attribute__((address_space(1))) float *)((const __attribute__((address_space(1))) char *)scalar_base(q + (long)(2 * r) * p.pl_pitch) + lo);
+            // (the planes are read once: non-temporal, they do not displace anything in L2 / the Infinity Cache;
+            // together with the non-temporal stores of MODE_L12: unfused 3840x2160 1.11-1.14 -> 1.05 ms)
+            d2n[r] = __builtin_nontemporal_load((const __attribute__((address_space(1))) float *)((const __attribute__((address_space(1))) char *)scalar_base(q + (long)(2 * r) * p.pl_pitch) + lo));
     };
     if constexpr (MODE == MODE_L3) load_planes_at((long)frame * p.pl_frame_pitch + (long)f_lo * p.pl_stride);
     // The drain step (the output rows the last feature row completes) sits behind the loop, not in an extra iteration
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                     const unsigned lo = lane_off(pl_lane * 4u);       // BYTE offset, 32 bits (host: pl_pitch < 2^29)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        *(__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)scalar_base(o + (long)(2 * r) * p.pl_pitch) + lo) = d2[r];
+                        // (written once, 1 GB per 3840x2160 frame: non-temporal)
+                        __builtin_nontemporal_store(d2[r], (__attribute__((address_space(1))) float *)((__attribute__((address_space(1))) char *)scalar_base(o + (long)(2 * r) * p.pl_pitch) + lo));
                 }
             }
         } else {
