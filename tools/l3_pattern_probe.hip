@@ -11,7 +11,7 @@
 
 constexpr int W = 3840, H = 2160, NP = 32;
 
-template <int UNITS>   // UNITS 32-pixel units per wave and row: strip = 4 waves x UNITS x 32 columns
+template <int UNITS, bool NT = false>   // UNITS 32-pixel units per wave and row: strip = 4 waves x UNITS x 32 columns; NT: non-temporal loads
 __global__ __launch_bounds__(256) void walk(const float *__restrict__ planes, unsigned char *__restrict__ out, int seg_rows)
 {
     constexpr int SW = 128 * UNITS;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void walk(const float *__restrict__ planes, un
         for (int u = 0; u < UNITS; ++u) {
             const float *q = planes + (long)min(y, H - 1) * W + strip * SW + (wave * UNITS + u) * 32 + j;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[u][r] = q[(long)(2 * r + half) * pitch];
+            for (int r = 0; r < 16; ++r) d[u][r] = NT ? __builtin_nontemporal_load(q + (long)(2 * r + half) * pitch) : q[(long)(2 * r + half) * pitch];
         }
     };
     load(y0, cur);
@@ -67,6 +67,20 @@ __global__ __launch_bounds__(256) void walk_x4(const float *__restrict__ planes,
     }
 }
 
+// reference: the same bytes as ONE linear stream (every workgroup a contiguous chunk, 16-byte loads)
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_x4(const float *__restrict__ planes, unsigned char *__restrict__ out, long n4_per_block)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *p = reinterpret_cast<const f4 *>(planes) + (long)blockIdx.x * n4_per_block;
+    f4 acc = {0, 0, 0, 0};
+    for (long i = threadIdx.x; i < n4_per_block; i += 256) {
+        const f4 v = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1;
+}
+
 template <typename F>
 static void run(const char *name, F launch, int blocks)
 {
@@ -102,6 +116,20 @@ int main()
         run(nm, [&] { hipLaunchKernelGGL(walk<2>, dim3(15 * segs), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, seg_rows); }, 15 * segs);
         std::snprintf(nm, sizeof nm, "dwordx4, 1-KB runs, %d-row segments", seg_rows);
         run(nm, [&] { hipLaunchKernelGGL(walk_x4, dim3(15 * segs), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, seg_rows); }, 15 * segs);
+    }
+    for (int seg_rows : {64, 135}) {
+        const int segs = (H + seg_rows - 1) / seg_rows;
+        char nm[96];
+        std::snprintf(nm, sizeof nm, "NON-TEMPORAL 512-B runs, %d-row segments", seg_rows);
+        run(nm, [&] { hipLaunchKernelGGL((walk<1, true>), dim3(30 * segs), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, seg_rows); }, 30 * segs);
+        std::snprintf(nm, sizeof nm, "NON-TEMPORAL 1-KB runs, %d-row segments", seg_rows);
+        run(nm, [&] { hipLaunchKernelGGL((walk<2, true>), dim3(15 * segs), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, seg_rows); }, 15 * segs);
+    }
+    {
+        const int blocks = 4096;
+        const long n4 = (long)frame / 4 / blocks;
+        run("linear stream, 16-byte loads", [&] { hipLaunchKernelGGL(stream_x4<false>, dim3(blocks), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, n4); }, blocks);
+        run("linear stream, non-temporal 16-byte loads", [&] { hipLaunchKernelGGL(stream_x4<true>, dim3(blocks), dim3(256), 0, 0, planes + (k++ % 3) * frame, out, n4); }, blocks);
     }
     for (int seg_rows : {16, 32}) {
         const int segs = (H + seg_rows - 1) / seg_rows;
