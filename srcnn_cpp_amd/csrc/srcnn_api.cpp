@@ -1559,7 +1559,17 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         return SRCNN_OK;
     }
     // at most 64 frames per launch: the seam scratch of a launch grows with its frames (25 MB each at 3840x2160)
-    constexpr int kMaxFrames = 64;
+    int kMaxFrames = 64;
+    // A small batch of LARGE planes runs fastest as one single-plane launch per frame (each with its balanced item plan,
+    // back to back on the stream) -- ms per frame, same box: 2 x 3840x2160 0.955 against 0.976 for one launch that repeats the
+    // item plan frame after frame, 8 x 0.956 / 0.959, 24 x 0.949 / 0.946; 8 x 5760x3240 2.119 / 2.137; 4 x 1920x1080 0.252
+    // against 0.275 on the regular grid, 8 x 0.253 / 0.258, 16 x 0.2525 / 0.252.  Larger batches (and small planes, which
+    // cannot fill the GPU alone) use one launch (64 x 3840x2160: 0.936 ms per frame).  profiles/r02/ablation.txt section 11.
+    static const char *env_loop = std::getenv("SRCNN_DEBUG_FRAMELOOP");      // experiment knob: 0 = never
+    const size_t px = (size_t)width * height;
+    if (c->mode == SRCNN_MODE_MFMA && n_frames > 1 && !(env_loop && std::atoi(env_loop) == 0) &&
+        ((px >= ((size_t)4 << 20) && n_frames <= 16) || (px >= ((size_t)3 << 19) && n_frames <= 8)))
+        kMaxFrames = 1;
     for (int f0 = 0; f0 < n_frames; f0 += kMaxFrames) {
         StripParams p{};
         p.src = d_src + (size_t)f0 * src_frame_pitch;
