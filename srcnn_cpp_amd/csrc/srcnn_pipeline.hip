@@ -182,8 +182,12 @@ __device__ __forceinline__ unsigned vpass4(const float (*hbuf)[256], int tx, int
 // the vertical pass reads its taps as one 16-byte LDS word per row and stores one dword per row: a quarter of the
 // store and LDS instructions of the kernel above (which remains the fallback for small scales / odd strides).
 // Same arithmetic, bit-identical results.
-constexpr int RT4 = 32;       // output rows per workgroup
-constexpr int RMAX4 = 28;     // source rows such a tile may span (host checks)
+#ifndef SRCNN_RT4
+#define SRCNN_RT4 32
+#endif
+constexpr int RT4 = SRCNN_RT4;          // output rows per workgroup (four row groups of RPT rows)
+constexpr int RPT = RT4 / 4;            // rows per thread
+constexpr int RMAX4 = RT4 == 32 ? 28 : 20;     // source rows such a tile may span (host checks)
 
 __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t *__restrict__ src, long sstride,
                                                                   long spitch, int sw, int sh,
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(256) void resize_cubic_tiled4_kernel(const uint8_t 
     const int tx = tid & 63, ty = tid >> 6;
     const int dx = dx0 + 4 * tx;
     if (dx >= dw) return;
-    for (int r = 0; r < 8; ++r) {
-        const int dy = dy0 + 8 * ty + r;
+    for (int r = 0; r < RPT; ++r) {
+        const int dy = dy0 + RPT * ty + r;
         if (dy >= dy1) break;
         const unsigned v = vpass4(hbuf, tx, yofs[dy] - 1 - r_lo, beta + 4 * dy, dx, dw);
         uint8_t *o = dst + (long)blockIdx.z * dpitch + (long)dy * dstride + dx;
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(256) void bgr_to_y_resized_kernel(const uint8_t *__
     stage_and_hpass(bgr, stride, sw, sh, dw, 0, g, xofs, alpha, sbuf, hbuf);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, dx = g.dx0 + 4 * tx;
     if (dx >= dw) return;
-    for (int r = 0; r < 8; ++r) {
-        const int dy = g.dy0 + 8 * ty + r;
+    for (int r = 0; r < RPT; ++r) {
+        const int dy = g.dy0 + RPT * ty + r;
         if (dy >= g.dy1) break;
         const unsigned v = vpass4(hbuf, tx, yofs[dy] - 1 - g.r_lo, beta + 4 * dy, dx, dw);
         uint8_t *o = dst + (long)dy * dstride + dx;
@@ -326,21 +330,21 @@ __global__ __launch_bounds__(256) void resize_merge_kernel(const uint8_t *__rest
     __shared__ uint8_t sbuf[RMAX4][SMAX];
     const TileGeom g = tile_geom(dw, dh, xofs, yofs);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, dx = g.dx0 + 4 * tx;
-    unsigned crcb[2][8];
+    unsigned crcb[2][RPT];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         if (pl) __syncthreads();            // every thread has finished reading plane 0's sums
         stage_and_hpass(bgr, stride, sw, sh, dw, 1 + pl, g, xofs, alpha, sbuf, hbuf);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int dy = min(g.dy0 + 8 * ty + r, g.dy1 - 1);
+        for (int r = 0; r < RPT; ++r) {
+            const int dy = min(g.dy0 + RPT * ty + r, g.dy1 - 1);
             crcb[pl][r] = vpass4(hbuf, tx, yofs[dy] - 1 - g.r_lo, beta + 4 * dy, min(dx, dw - 1), dw);
         }
     }
     if (dx >= dw) return;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int dy = g.dy0 + 8 * ty + r;
+    for (int r = 0; r < RPT; ++r) {
+        const int dy = g.dy0 + RPT * ty + r;
         if (dy >= g.dy1) break;
         const uint8_t *yrow = ysr + (long)dy * ystride + dx;
         uint8_t *o = out + (long)dy * ostride + 3L * dx;
