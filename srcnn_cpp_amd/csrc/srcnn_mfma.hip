@@ -381,9 +381,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // rows with everything that depends on f & 3 a compile-time constant: the F-tile slot (LDS offsets become immediates), one
     // in-place chain update without the image-top / image-bottom / seam-export cases, and the horizontal sums, stores and
     // column-seam exports of TWO finished rows at once every second row -- lane-half 0 takes output row f - 3, lane-half 1
-    // row f - 4 (in the general body both halves compute the same row).  The rows at either end of a work item (the first six,
-    // which export to the seam above or see the image top, and whatever is left behind the last multiple of four, including the
-    // image's bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
+    // row f - 4 (in the general body both halves compute the same row).  The rows at either end of a work item (the first six or
+    // seven, which export to the seam above or see the image top, and at most one row behind the last pair, or the image's
+    // bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
     constexpr bool FASTK = fast_kernel(MODE, PRE, DIAG, ABL);
     constexpr int FSLOT = 6 * FW;                 // floats per F-tile slot
     int xn[5] = {0, 0, 0, 0, 0};
