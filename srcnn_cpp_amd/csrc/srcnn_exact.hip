@@ -143,9 +143,8 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
                                                            const float *__restrict__ kernel, float bias)
 {
     constexpr int TW = 64, TH = 4, WW = TW + 4, WH = TH + 4, WN = WW * WH;   // 68 x 8 window
-    __shared__ float kw[800];
     __shared__ float win[2][WN];
-    for (int q = threadIdx.x; q < 800; q += 256) kw[q] = kernel[q];
+    const float *kw = kernel;          // wave-uniform index: the weights come through the scalar cache (from LDS: 2 % slower)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col0 = blockIdx.x * TW, row0 = blockIdx.y * TH;
     const int col = col0 + tx, row = row0 + ty;
