@@ -95,3 +95,27 @@ def test_config4_5760x3240_frame_stream(gpu_ctx, weights_blob):
     assert shas([gpu_ctx.forward_y(frames[3])]) == [pin["gpuorder_sha256"][3]]
     for k in (0, 4, 7):
         check_against_reference(streamed[k], frames[k], weights_blob)
+
+
+@pytest.mark.parametrize("n_frames", [3, 20])
+def test_batch_launch_forms_equal_single_plane(gpu_ctx, weights_blob, n_frames):
+    """How a batch is launched depends on its size (csrc/srcnn_api.cpp): a few large planes run as one single-plane launch
+    per frame, 17-31 of them as ONE launch that repeats the plane's work items -- row seams, column seams, the merged seam
+    kernel over all frames -- frame after frame, larger batches on the regular grid.  Whatever the form, every frame must
+    come out as it does launched alone (which the other tests pin to the model of the kernels' arithmetic)."""
+    import torch
+    w, h = 2304, 1830                               # 4.2 MPix: 18 strips, ~64-row items
+    frames = synth_batch(w, h, n_frames, first_frame=40)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.full_like(d_in, 3)
+    d_one = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.forward_y_dev(d_in.data_ptr(), w, h * w, d_out.data_ptr(), w, h * w, w, h, n_frames)
+    gpu_ctx.synchronize()
+    out = d_out.cpu().numpy()
+    for k in sorted({0, 1, n_frames // 2, n_frames - 1}):
+        gpu_ctx.forward_y_dev(d_in[k].data_ptr(), w, h * w, d_one.data_ptr(), w, h * w, w, h, 1)
+        gpu_ctx.synchronize()
+        assert np.array_equal(out[k], d_one.cpu().numpy()), k
+    model, _ = oracle.gpuorder_forward_y(frames[n_frames - 1][:200], weights_blob)
+    assert np.array_equal(out[n_frames - 1][:190], model[:190])         # 13x13 locality: the top rows of a crop are the frame's
