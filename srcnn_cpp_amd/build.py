@@ -33,8 +33,10 @@ UNITS = [
     # MFMA results are consumed by vector instructions: keep them in architectural VGPRs (the 1-wave/SIMD
     # variant pins its weight fragments to AGPRs instead)
     ("srcnn_split16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
-    ("srcnn_exact.hip", ["-ffp-contract=off"]),
-    ("srcnn_pipeline.hip", []),
+    # ... and no SLP packing either: v_pk_mul_f32 / v_pk_add_f32 run no faster than two plain instructions here (measured:
+    # SRCNN_MODE_EXACT 2.92 -> 2.81 ms without them; a hand-packed layer-1 product made it 3.09)
+    ("srcnn_exact.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
+    ("srcnn_pipeline.hip", ["-fno-slp-vectorize"]),
     ("srcnn_api.cpp", ["-x", "hip"]),
 ]
 
