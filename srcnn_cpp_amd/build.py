@@ -36,7 +36,9 @@ UNITS = [
     # ... and no SLP packing either: v_pk_mul_f32 / v_pk_add_f32 run no faster than two plain instructions here (measured:
     # SRCNN_MODE_EXACT 2.92 -> 2.81 ms without them; a hand-packed layer-1 product made it 3.09)
     ("srcnn_exact.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
-    ("srcnn_pipeline.hip", ["-fno-slp-vectorize"]),
+    # the resize's vertical pass is OpenCV's float32 multiply-then-add (every product and sum rounded on its own):
+    # __fmul_rn / __fadd_rn are plain * and + in HIP's headers, so contraction must be off here too
+    ("srcnn_pipeline.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
     ("srcnn_api.cpp", ["-x", "hip"]),
 ]
 

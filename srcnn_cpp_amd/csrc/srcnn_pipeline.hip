@@ -11,6 +11,10 @@
 // no LDS, consecutive lanes on consecutive bytes.
 #include "srcnn_kernels.h"
 
+// No FMA contraction anywhere in this file (also given on the command line, srcnn_cpp_amd/build.py): the vertical pass of
+// the resize reproduces OpenCV's separately rounded float32 products and sums.
+#pragma clang fp contract(off)
+
 namespace srcnn {
 
 __device__ __forceinline__ int descale14(int x) { return (x + (1 << 13)) >> 14; }

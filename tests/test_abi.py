@@ -110,15 +110,22 @@ def test_python_binding_validates_planes():
     assert stride == 8
 
 
-def test_exact_kernels_have_no_fused_multiply_add(tmp_path):
-    """srcnn_exact.hip must keep the reference's multiply-then-add arithmetic."""
+@pytest.mark.parametrize("unit", ["srcnn_exact.hip", "srcnn_pipeline.hip"])
+def test_exact_kernels_have_no_fused_multiply_add(tmp_path, unit):
+    """srcnn_exact.hip must keep the reference's multiply-then-add arithmetic, srcnn_pipeline.hip OpenCV's separately
+    rounded float32 products and sums in the resize's vertical pass (HIP's __fmul_rn / __fadd_rn are plain * and +, so
+    only the build flag keeps them apart).  Compiled with the flags the build uses (srcnn_cpp_amd/build.py)."""
     import subprocess
-    out = tmp_path / "exact.s"
-    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
-                    "--cuda-device-only", "-o", str(out), str(B.CSRC / "srcnn_exact.hip")],
+    flags = dict(B.UNITS)[unit]
+    assert "-ffp-contract=off" in flags
+    out = tmp_path / "unit.s"
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S",
+                    "--cuda-device-only", "-o", str(out), str(B.CSRC / unit)],
                    check=True, stderr=subprocess.DEVNULL)
     asm = out.read_text()
-    assert "v_mul_f32" in asm and "v_add_f32" in asm and "v_add_f64" in asm
+    assert "v_mul_f32" in asm and "v_add_f32" in asm
+    if unit == "srcnn_exact.hip":
+        assert "v_add_f64" in asm
     for banned in ("v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_mad_f32", "v_pk_fma_f32", "v_fma_f64",
                    "v_fma_mix"):
         assert banned not in asm, banned
