@@ -173,6 +173,9 @@ __device__ __forceinline__ void cseam_export(const float *tile, float *dst, int 
     if (cl.cnt > 0) dst[(unsigned)e] = v;
 }
 
+// (The packed multiply below reads accumulator registers a few cycles behind the MFMA that writes them, inside inline asm the
+// compiler's hazard recogniser does not look into: the hardware interlocks that read -- tools/mfma_interlock_probe.hip,
+// profiles/r02/mfma_interlock_probe.txt: a v_add_f32 issued directly behind a 64-cycle MFMA returns the finished result.)
 // ReLU of TWO registers in one instruction.  The host scales layers 1 and 2 by exact powers of two so that every
 // activation is <= 1 for any 8-bit input (srcnn_kernels.h); v_pk_mul_f32 by 1.0 with the clamp bit then returns
 // min(max(x, 0), 1) = max(x, 0), the reference's (x < 0) ? 0 : x (src/srcnn.cpp:304,319).
