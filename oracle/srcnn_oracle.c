@@ -6,8 +6,8 @@
  * and bench.py's cpu_baseline leg may load this library, and only as the
  * checker / the reported CPU baseline -- never as something the product calls.
  *
- * PARITY PIN STATUS: pinned against the reference's ONE output artefact; not
- * pinned by reference test vectors (there are none).
+ * PARITY PIN STATUS: PINNED EXACTLY against the reference's one output artefact;
+ * not pinned by reference test vectors (there are none).
  *   The reference has no tests or golden vectors for this path (src/test.cpp
  *   belongs to another library and never compares pixels), and its
  *   src/srcnn.cpp cannot be compiled in this image: it includes OpenCV headers
@@ -15,15 +15,18 @@
  *   headers is not allowed -- so no output of a reference BINARY run here
  *   exists.  What the reference does hold is Pictures/butterfly-srcnn.png, its
  *   own result for `srcnn --scale=1.5 butterfly.png` (README.md:39-45).  With
- *   the OpenCV steps around the path restated (oracle/opencv_steps.c), this
- *   restatement reproduces that picture EXACTLY on 99.81 % of its RGB pixels,
- *   max |diff| 2, PSNR 75.3 dB (bicubic alone: 32.8 dB) --
- *   tests/test_pipeline_oracle.py; the 0.19 % residual is consistent with
- *   OpenCV SIMD builds running the resize's vertical pass in float.  A wrong tap
- *   order, border rule, weight layout or truncation here would move thousands
- *   of pixels.  In addition the file is cross-checked bitwise by an independent
- *   numpy float32 restatement (tests/test_oracle_numpy.py).  Bit-level parity
- *   with a reference binary on arbitrary inputs remains unproven.
+ *   the OpenCV steps around the path restated (oracle/opencv_steps.c: the
+ *   resize's vertical pass in float32 for the columns OpenCV's x86 SIMD functor
+ *   covers, fixed point for the width % 8 tail), the whole pipeline region
+ *   src/srcnn.cpp:505-659 on this restatement reproduces that picture BIT FOR
+ *   BIT: all 576 x 576 x 3 = 995,328 bytes (tests/test_pipeline_oracle.py;
+ *   bicubic alone is 32.8 dB away; round 1's all-fixed-point vertical pass
+ *   left 0.19 % of the pixels off by one, each of them attributed in that test).
+ *   A wrong tap order, border rule, weight layout or truncation here would move
+ *   thousands of pixels.  Beyond that one image the file is cross-checked
+ *   bitwise by an independent numpy float32 restatement
+ *   (tests/test_oracle_numpy.py) and by structural identities (fused ==
+ *   64 x conv99 -> 32 x conv11, crop locality, constant planes).
  *
  * Arithmetic of record: what the shipped Makefile produces (objects are
  * compiled with no -O flag and without -ffast-math, Makefile:21-23,43), i.e.

@@ -29,6 +29,7 @@ __all__ = [
     "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
     "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "FLOP_PER_PIXEL",
+    "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
     "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
 
@@ -46,6 +47,7 @@ N_WEIGHTS = 8129
 # 2 x (64*81 + 32*64 + 32*25) MAC per output pixel
 FLOP_PER_PIXEL = 16064
 
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_STATE = -1, -2, -3, -4, -5      # include/srcnn_amd.h
 _ERR = {-1: "invalid argument", -2: "HIP runtime error", -3: "out of memory",
         -4: "no gfx950 device", -5: "bad state"}
 

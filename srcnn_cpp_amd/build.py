@@ -22,8 +22,6 @@ OBJ = PKG.parent / ("build" + (f"_{VARIANT}" if VARIANT else ""))
 ARCH = "gfx950"
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 COMMON += os.environ.get("SRCNN_BUILD_DEFINES", "").split()
-if os.environ.get("SRCNN_ABLATION_BUILD"):      # timing-only ablation kernels (profiles/rNN/ablation.txt); never shipped
-    COMMON.append("-DSRCNN_ABLATION_BUILD")
 # (source, extra flags).  srcnn_exact.hip reproduces the reference's
 # multiply-then-add arithmetic: contraction to FMA must stay off there.
 UNITS = [

@@ -38,7 +38,7 @@ struct srcnn_ctx {
     hipStream_t stream = nullptr;
     char err[512] = "no error";
     // model
-    bool has_weights = false;
+    bool has_l12 = false, has_l3 = false;   // which layers of the uploaded tables came from the caller (the rest are zeros)
     float b3 = 0.f;
     DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
     DevBuf wfrag16; // split-f16 fragments (SRCNN_MODE_SPLIT16), S16_TABLE_BYTES
@@ -338,6 +338,11 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     std::memcpy(c->host_raw.data(), raw.data(), 8129 * sizeof(float));
     return SRCNN_OK;
 }
+
+// The whole-path entry points need all three layers.  srcnn_conv99x11 / srcnn_conv55 (the reference surface) load only the
+// layers they are given -- the others stay zero -- and must not make a later srcnn_forward_y run on half a model.
+bool has_model(const srcnn_ctx *c) { return c->has_l12 && c->has_l3; }
+const char *const kNoModel = "the model is not loaded: srcnn_set_weights not called (srcnn_conv99x11 / srcnn_conv55 load only their own layers)";
 
 // Do two element ranges of the same device address space overlap?  (first byte, one past the last byte)
 bool ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes)
@@ -871,14 +876,39 @@ bool cseam_pays(int width)
     return ns_cs < ns_halo && (width - (ns_cs - 1) * FW >= 4 || ns_cs == 1);
 }
 
+// How many frames of a batch go into ONE launch of the fused kernel (srcnn_forward_y_dev; srcnn_query_plan reports the same).
+// * A small batch of LARGE planes runs fastest as one single-plane launch per frame (each with its balanced item plan, back
+//   to back on the stream) -- ms per frame, same box: 2 x 3840x2160 0.955 against 0.976 for one launch that repeats the item
+//   plan frame after frame, 8 x 0.956 / 0.959, 24 x 0.949 / 0.946; 8 x 5760x3240 2.119 / 2.137; 4 x 1920x1080 0.252 against
+//   0.275 on the regular grid, 8 x 0.253 / 0.258, 16 x 0.2525 / 0.252 (profiles/r02/ablation.txt section 11).
+// * Other batches below kItemBatchMax frames repeat the plane's item plan frame after frame in one launch, whose row-seam
+//   scratch is (2 n_cu - n_strips) seams x 43 KB per frame whatever the plane's size (21 MB at 3840x2160, + 4 MB of column
+//   seams): at most kItemBatchChunk frames per launch, 200 MB of context-owned scratch per stream instead of 770 MB at 31.
+// * Larger batches use the regular strip x segment x frame grid (column-seam scratch only, 4 MB per 3840x2160 frame),
+//   at most 64 frames per launch.
+constexpr int kItemBatchMax = 32, kItemBatchChunk = 8, kGridBatchChunk = 64;
+int frames_per_launch(const srcnn_ctx *c, int width, int height, int n_frames)
+{
+    static const char *env_loop = std::getenv("SRCNN_DEBUG_FRAMELOOP");      // experiment knob: 0 = never one launch per frame
+    const size_t px = (size_t)width * height;
+    if (c->mode != SRCNN_MODE_MFMA || n_frames <= 1) return kGridBatchChunk;
+    if (!(env_loop && std::atoi(env_loop) == 0) &&
+        ((px >= ((size_t)4 << 20) && n_frames < kItemBatchMax) || (px >= ((size_t)3 << 19) && n_frames <= 8)))
+        return 1;
+    return n_frames < kItemBatchMax ? kItemBatchChunk : kGridBatchChunk;
+}
+
 // Common launch of the three strip modes on device memory.
 int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
 {
     const int halo = (mode == MODE_L12) ? 0 : 2;
-    // undocumented experiment knobs (never set in production)
+    // Undocumented experiment knobs (never set in production).  Only bits that leave every output byte as it is are honoured:
+    // 2 / 16 = the stamped builds of the split-f16 / float32 production kernel (tools/diag_split16.py, diag_light.py), 8 = no XCD remap,
+    // 128 = small batches on the regular grid.  A stray SRCNN_DEBUG_TUNE cannot change a pixel (tests/test_gpu_parity.py).
     static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
     static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
-    p.tune = env_tune ? std::atoi(env_tune) : 0;
+    constexpr int kTuneHarmless = 2 | 8 | 16 | 128;
+    p.tune = (env_tune ? std::atoi(env_tune) : 0) & kTuneHarmless;
     const size_t pad = env_pad ? (size_t)std::atol(env_pad) : 0;
     const bool split16 = mode == MODE_FUSED && c->mode == SRCNN_MODE_SPLIT16;
     const int wgs_per_cu = split16_wgs_per_cu(split16, p.tune);
@@ -926,13 +956,13 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     // A small batch repeats the plane's item plan frame after frame in one launch (no halo rows, and the next frame's
     // blocks fill the CUs the last items of a frame leave idle): 8 x 3840x2160 0.857 against 0.839 on the regular
     // grid; from kItemBatchMax frames on the regular grid's tall segments are as good (64 frames: 0.863 vs 0.865).
-    constexpr int kItemBatchMax = 32;
-    if (mode != MODE_L12 && (n_frames == 1 || (fused32 && n_frames < kItemBatchMax && !(p.tune & (2 | 128)))) && !l3_aligned) {   // tune 128: regular grid (A/B)
+    // (srcnn_forward_y_dev hands over at most kItemBatchChunk frames of such a batch per call: frames_per_launch())
+    if (mode != MODE_L12 && (n_frames == 1 || (fused32 && n_frames < kItemBatchMax && !(p.tune & 128))) && !l3_aligned) {   // tune 128: regular grid (A/B)
         // float32 fused kernel only: seams instead of halo rows between the items of a strip, and column seams
         // instead of halo columns between strips (srcnn_kernels.h).  SRCNN_DEBUG_SEAMS: 0 = neither, 1 = rows only.
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
         const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
-        const bool want_seams = mode == MODE_FUSED && !split16 && (seam_knob & 1) && !(p.tune & 2);
+        const bool want_seams = mode == MODE_FUSED && !split16 && (seam_knob & 1);
         int rc;
         // a plane too small for two items per CU of useful height: one (taller) item per CU still beats the regular grid
         // with its halo rows
@@ -989,7 +1019,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     }
     // Batches (regular grid): column seams only -- the planner already makes the segments tall, and a row seam
     // costs 74 KB of scratch.
-    if (fused32 && n_frames > 1 && !(p.tune & 2) && grid_items == 0) {
+    if (fused32 && n_frames > 1 && grid_items == 0) {
         static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
         const int ns_cs = (p.width + FW - 1) / FW;
         (void)ns_cs;
@@ -1028,7 +1058,6 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
     }
     else HIP_TRY(c, launch_strip(mode, p, n_frames, c->stream, pad));
-    if (p.tune & 32) return SRCNN_OK;          // timing experiment: strip kernel only (wrong pixels next to the seams)
     // Row seams and column seams in ONE launch when the plan keeps the seam windows of neighbouring strips apart
     // (plan_items_balanced()): the blocks that finish a row seam then also finish the column-seam pixels of their four
     // rows, the column-seam blocks skip those rows, and neither waits for the other.
@@ -1337,11 +1366,11 @@ int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const fl
     if (!k99 || !b99 || !k11 || !b11 || !k55) return fail(c, SRCNN_ERR_INVALID, "null weight table");
     // a caller that passes its const tables on every call (the reference does, src/srcnn.cpp:609,627) packs and uploads once
     const float *hr = c->host_raw.data();
-    if (c->has_weights && hr[7328] == b55 && !std::memcmp(hr, b99, 64 * 4) && !std::memcmp(hr + 64, k99, 5184 * 4) &&
+    if (c->has_l12 && c->has_l3 && hr[7328] == b55 && !std::memcmp(hr, b99, 64 * 4) && !std::memcmp(hr + 64, k99, 5184 * 4) &&
         !std::memcmp(hr + 5248, b11, 32 * 4) && !std::memcmp(hr + 5280, k11, 2048 * 4) && !std::memcmp(hr + 7329, k55, 800 * 4))
         return SRCNN_OK;
     if ((rc = upload_weights(c, k99, b99, k11, b11, k55, b55))) return rc;
-    c->has_weights = true;
+    c->has_l12 = c->has_l3 = true;
     return SRCNN_OK;
 }
 
@@ -1376,30 +1405,31 @@ extern "C" int srcnn_debug_plan_items(int n_cu, int n_strips, int row_begin, int
 int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[6])
 {
     if (!c || !out || width <= 0 || height <= 0 || n_frames <= 0) return SRCNN_ERR_INVALID;
-    static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
     static const char *env_seams = std::getenv("SRCNN_DEBUG_SEAMS");
-    const int wgs_per_cu = split16_wgs_per_cu(c->mode == SRCNN_MODE_SPLIT16, env_tune ? std::atoi(env_tune) : 0);
-    // mirrors run_strip(): the float32 fused kernel uses column seams (strips of FW columns) when the geometry allows
+    const int wgs_per_cu = split16_wgs_per_cu(c->mode == SRCNN_MODE_SPLIT16, 0);
+    // mirrors srcnn_forward_y_dev() and run_strip(): `nl` frames go into one launch (1 = one single-plane launch per frame);
+    // the float32 fused kernel uses column seams (strips of FW columns) when the geometry allows
+    const int nl = std::min(n_frames, frames_per_launch(c, width, height, n_frames));
     const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
     const int ns_cs = (width + FW - 1) / FW;
-    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (n_frames > 1 || (seam_knob & 1)) && cseam_pays(width);
+    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (nl > 1 || (seam_knob & 1)) && cseam_pays(width);
     int items_per_cu = wgs_per_cu;
     const bool row_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 1);
     auto fits = [&](int n_strips_, int per_cu) { return !plan_items(c->n_cu, n_strips_, 0, height, skew_percent(), per_cu, row_seams).items.empty(); };
-    if (col_seams && n_frames == 1 && !fits(ns_cs, wgs_per_cu)) {
+    if (col_seams && nl == 1 && !fits(ns_cs, wgs_per_cu)) {
         if (wgs_per_cu == 2 && fits(ns_cs, 1)) items_per_cu = 1;
         else col_seams = false;
     }
-    if (!col_seams && n_frames == 1 && row_seams && wgs_per_cu == 2) {
+    if (!col_seams && nl == 1 && row_seams && wgs_per_cu == 2) {
         const int ns_halo = (width + FW - 5) / (FW - 4);
         if (!fits(ns_halo, 2) && fits(ns_halo, 1)) items_per_cu = 1;
     }
-    const Plan pl = make_plan(c, width, height, n_frames, 2, wgs_per_cu, col_seams ? 0 : -1);
-    out[0] = pl.n_strips * pl.n_segs * n_frames;
+    const Plan pl = make_plan(c, width, height, nl, 2, wgs_per_cu, col_seams ? 0 : -1);
+    out[0] = pl.n_strips * pl.n_segs * n_frames;      // over all launches of the batch
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
-    if (n_frames == 1 || (c->mode == SRCNN_MODE_MFMA && n_frames < 32)) {   // explicit work items (plan_items), repeated per frame of a small batch
+    if (nl == 1 || (c->mode == SRCNN_MODE_MFMA && n_frames < kItemBatchMax)) {   // explicit work items (plan_items), repeated per frame of a small batch
         const std::vector<int> items =
             plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), items_per_cu,
                        c->mode == SRCNN_MODE_MFMA && (seam_knob & 1)).items;
@@ -1423,7 +1453,7 @@ int srcnn_conv99x11_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, f
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!c->has_l12) return fail(c, SRCNN_ERR_STATE, "layers 1-2 not loaded (srcnn_set_weights / srcnn_conv99x11)");
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_planes, plane_stride, width, height) ||
         plane_pitch < plane_stride * (size_t)height || bad_pitch(plane_pitch))
         return fail(c, SRCNN_ERR_INVALID, "conv99x11_dev: bad plane geometry");
@@ -1452,7 +1482,7 @@ int srcnn_conv55_dev(srcnn_ctx *c, const float *d_planes, size_t plane_stride, s
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!c->has_l3) return fail(c, SRCNN_ERR_STATE, "layer 3 not loaded (srcnn_set_weights / srcnn_conv55)");
     if (bad_plane(d_planes, plane_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         plane_pitch < plane_stride * (size_t)height || bad_pitch(plane_pitch))
         return fail(c, SRCNN_ERR_INVALID, "conv55_dev: bad plane geometry");
@@ -1483,7 +1513,7 @@ int srcnn_forward_y_unfused_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_s
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || !d_work ||
         n_frames <= 0)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_unfused_dev: bad arguments");
@@ -1534,7 +1564,7 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         n_frames <= 0)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: bad arguments");
@@ -1558,18 +1588,8 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         }
         return SRCNN_OK;
     }
-    // at most 64 frames per launch: the seam scratch of a launch grows with its frames (25 MB each at 3840x2160)
-    int kMaxFrames = 64;
-    // A small batch of LARGE planes runs fastest as one single-plane launch per frame (each with its balanced item plan,
-    // back to back on the stream) -- ms per frame, same box: 2 x 3840x2160 0.955 against 0.976 for one launch that repeats the
-    // item plan frame after frame, 8 x 0.956 / 0.959, 24 x 0.949 / 0.946; 8 x 5760x3240 2.119 / 2.137; 4 x 1920x1080 0.252
-    // against 0.275 on the regular grid, 8 x 0.253 / 0.258, 16 x 0.2525 / 0.252.  Larger batches (and small planes, which
-    // cannot fill the GPU alone) use one launch (64 x 3840x2160: 0.936 ms per frame).  profiles/r02/ablation.txt section 11.
-    static const char *env_loop = std::getenv("SRCNN_DEBUG_FRAMELOOP");      // experiment knob: 0 = never
-    const size_t px = (size_t)width * height;
-    if (c->mode == SRCNN_MODE_MFMA && n_frames > 1 && !(env_loop && std::atoi(env_loop) == 0) &&
-        ((px >= ((size_t)4 << 20) && n_frames <= 16) || (px >= ((size_t)3 << 19) && n_frames <= 8)))
-        kMaxFrames = 1;
+    // the seam scratch of a launch grows with its frames: frames_per_launch() bounds it
+    const int kMaxFrames = frames_per_launch(c, width, height, n_frames);
     for (int f0 = 0; f0 < n_frames; f0 += kMaxFrames) {
         StripParams p{};
         p.src = d_src + (size_t)f0 * src_frame_pitch;
@@ -1595,7 +1615,7 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) ||
         row_begin < 0 || row_end > height || row_begin >= row_end ||
         src_row0 > std::max(0, row_begin - 6) || dst_row0 > row_begin || src_row0 < 0 || dst_row0 < 0)
@@ -1626,7 +1646,7 @@ int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_s
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     if (!src || !dst || n_frames <= 0 || width <= 0 || height <= 0 || src_stride < (size_t)width ||
         dst_stride < (size_t)width)
         return fail(c, SRCNN_ERR_INVALID, "forward_y_frames: bad arguments");
@@ -1699,7 +1719,7 @@ int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t
 {
     BIND(c);
     int rc = SRCNN_OK;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     if (bad_plane(src, src_stride, width, height) || bad_plane(dst, dst_stride, width, height) ||
         (preclamp && preclamp_stride < (size_t)width))
         return fail(c, SRCNN_ERR_INVALID, "forward_y: bad plane geometry");
@@ -1789,12 +1809,12 @@ int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *
     // Layers 1-2 of the model are replaced, layer 3 of any loaded model is kept.  The reference passes the same
     // const tables on every call (src/srcnn.cpp:609): tables equal to the uploaded ones are not packed again.
     const float *hr = c->host_raw.data();
-    const bool same = c->has_weights && !std::memcmp(hr, bias99, 64 * 4) && !std::memcmp(hr + 64, kernel99, 5184 * 4) &&
+    const bool same = c->has_l12 && !std::memcmp(hr, bias99, 64 * 4) && !std::memcmp(hr + 64, kernel99, 5184 * 4) &&
                       !std::memcmp(hr + 5248, bias11, 32 * 4) && !std::memcmp(hr + 5280, kernel11, 2048 * 4);
     if (!same) {
         const std::vector<float> w3(hr + 7329, hr + 8129);      // upload_weights rewrites host_raw
         if ((rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), c->b3))) return rc;
-        c->has_weights = true;
+        c->has_l12 = true;
     }
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->in_u8, n))) return rc;
@@ -1818,12 +1838,12 @@ int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8
         if (!src[k]) return fail(c, SRCNN_ERR_INVALID, "conv55: null input plane %d", k);
     // layer 3 of the model is replaced; layers 1-2 of any loaded model are kept (src/srcnn.cpp:627)
     const float *hr = c->host_raw.data();
-    const bool same = c->has_weights && hr[7328] == bias && !std::memcmp(hr + 7329, kernel, 800 * 4);
+    const bool same = c->has_l3 && hr[7328] == bias && !std::memcmp(hr + 7329, kernel, 800 * 4);
     if (!same) {
         const std::vector<float> raw(c->host_raw);               // upload_weights rewrites host_raw
         if ((rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias)))
             return rc;
-        c->has_weights = true;
+        c->has_l3 = true;
     }
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
@@ -1973,7 +1993,7 @@ int srcnn_process_bgr_dev(srcnn_ctx *c, const uint8_t *d_bgr, size_t stride, int
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     int ow = 0, oh = 0;
     if (!d_bgr || !d_out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
         srcnn_scaled_size(width, height, scale, &ow, &oh) != SRCNN_OK || out_stride < 3 * (size_t)ow)
@@ -1987,7 +2007,7 @@ int srcnn_process_bgr(srcnn_ctx *c, const uint8_t *bgr, size_t stride, int width
     BIND(c);
     int rc = SRCNN_OK;
     (void)rc;
-    if (!c->has_weights) return fail(c, SRCNN_ERR_STATE, "srcnn_set_weights not called");
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     int ow = 0, oh = 0;
     if (!bgr || !out || width <= 0 || height <= 0 || stride < 3 * (size_t)width ||
         srcnn_scaled_size(width, height, scale, &ow, &oh) != SRCNN_OK || out_stride < 3 * (size_t)ow)
@@ -2028,7 +2048,7 @@ int check_ctx_set(srcnn_ctx *const *ctxs, int n_ctx)
     if (!ctxs || n_ctx <= 0) return SRCNN_ERR_INVALID;
     for (int k = 0; k < n_ctx; ++k) {
         if (!ctxs[k]) return SRCNN_ERR_INVALID;
-        if (!ctxs[k]->has_weights) return fail(ctxs[k], SRCNN_ERR_STATE, "srcnn_set_weights not called");
+        if (!has_model(ctxs[k])) return fail(ctxs[k], SRCNN_ERR_STATE, "%s", kNoModel);
         for (int j = 0; j < k; ++j)
             if (ctxs[j] == ctxs[k]) return fail(ctxs[k], SRCNN_ERR_INVALID, "the same context appears twice");
     }

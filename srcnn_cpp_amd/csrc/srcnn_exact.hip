@@ -10,7 +10,7 @@
 //
 // This translation unit MUST be compiled with -ffp-contract=off (the build
 // does so); the pragma below is a second line of defence.  No v_fma / v_mac /
-// v_fmac may appear in these kernels' ISA (checked by tests/test_build.py).
+// v_fmac may appear in these kernels' ISA (checked by tests/test_abi.py).
 #include "srcnn_kernels.h"
 
 #pragma clang fp contract(off)

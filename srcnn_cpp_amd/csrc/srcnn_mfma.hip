@@ -70,12 +70,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// Build-time experiment switches (same-box A/B builds, tools/ab.sh; profiles/r02/ablation.txt section 7)
-#ifndef SRCNN_EXP
-#define SRCNN_EXP 0
-#endif
-constexpr int EXP = SRCNN_EXP;
-
 // The first MFMA of a chain whose B operand a packed-multiply (inline asm) has just produced, written as inline asm
 // too: the compiler's hazard recogniser does not count inline-asm statements as wait states, sees the previous chain's
 // last MFMA "right before" this one and pads with s_nop 13 / s_nop 9 (56 / 40 idle cycles per wave-row) although
@@ -192,23 +186,18 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 
 // Kernels whose steady-state rows run through the FAST row body (see the row loop).  Convolution55 alone (MODE_L3) is
 // bound by its plane loads: the FAST body measured 0-1 % slower there (112 registers instead of 93), so it keeps the general one.
-constexpr bool fast_kernel(int mode, bool pre, int diag, int abl)
+constexpr bool fast_kernel(int mode, bool pre, int diag)
 {
-    return mode == MODE_FUSED && !pre && diag == 0 && abl == 0 && !(EXP & 1);
+    return mode == MODE_FUSED && !pre && diag == 0;
 }
 
-// DIAG: 1 = cycle stamps around every phase of every row (SRCNN_DEBUG_TUNE & 2; perturbs the timing, runs without
-// seams), 2 = four wall-clock stamps per wave -- entry, loop start, loop end, exit -- on the production launch
-// (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output.
-// ABL != 0: timing-only ablation builds (WRONG results by construction; SRCNN_DEBUG_TUNE bits 8..12 select one,
-// profiles/r02/ablation.txt): 1 no row barrier, 2 no layer-3 vertical / horizontal sums, 4 no ReLU / bias vector
-// instructions, 8 no Y staging, 16 layer-1 B operands from a register instead of LDS, 32 half as many B-operand reads,
-// 64 no column-seam export, 128 no horizontal sums / stores (layer-3 chains kept), 256 no layer-3 chains (horizontal sums kept),
-// 512 (with 4) the 24 ReLU instructions as independent single instructions between the layer-1 MFMAs instead of two bursts.
-template <int MODE, bool PRE, int DIAG = 0, int ABL = 0>
+// DIAG = 2: four wall-clock stamps per wave -- entry, loop start, loop end, exit -- beside the production code
+// (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output; the pixels are the production ones.
+// (The timing-only ablation kernels of rounds 1-2 -- wrong pixels by construction -- and the per-row stamp build are gone
+// from this file; profiles/r02/ablation.txt names the commit that still has them.)
+template <int MODE, bool PRE, int DIAG = 0>
 __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
-    if (p.tune & 64) return;        // timing experiment: what an empty launch of this grid costs
     unsigned long long lt[4] = {0, 0, 0, 0};
     if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -263,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     const bool cs = (MODE != MODE_L12) && p.cseam != nullptr;
     // export slots: lanes 0..14 of wave 0 (and, for the two-rows-at-once form of the FAST body, lanes 32..46 as well)
     const CseamLane cl = cseam_lane((cs && threadIdx.x < 64 && (threadIdx.x & 31) < 15 &&
-                                     (threadIdx.x < 32 || fast_kernel(MODE, PRE, DIAG, ABL)))
+                                     (threadIdx.x < 32 || fast_kernel(MODE, PRE, DIAG)))
                                         ? (int)(threadIdx.x & 31) : 15);
     const int halo_c = cs ? 0 : HALO;
     const int xs = strip * (FW - 2 * halo_c);   // first output column of the strip
@@ -315,8 +304,13 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         srcf = p.src + (long)frame * p.src_frame_pitch;
         ycol = clampi(gx0 - 4 + tid, 0, W - 1);
     }
+    // Y rows beyond f_hi + 3 feed no feature row of this block.  The row loop's prefetch stops there, so that a launch on a
+    // row stripe reads nothing outside the rows its caller must provide, [row_begin - 6, row_end + 6)
+    // (include/srcnn_amd.h, srcnn_forward_y_rows_dev): the ring slots behind y_last hold copies of that row, which
+    // nothing consumes.
+    const int y_last = min(H - 1, f_hi + 3);
     auto load_y = [&](int r) -> uint8_t {
-        const int rr = clampi(r, 0, H - 1) - p.src_row0;
+        const int rr = clampi(r, 0, y_last) - p.src_row0;
         const uint8_t *row = srcf + (long)rr * p.src_stride;      // uniform: scalar base + the lane's column
         return row[(unsigned)ycol];
     };
@@ -354,17 +348,6 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(w3f[q]));
     }
 
-    // DIAG build only (SRCNN_DEBUG_TUNE & 2): cycle stamps -> p.sink, never an output
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-        return t;
-    };
-    unsigned long long dg_t0 = 0, dg_r0 = 0, dg_l1 = 0, dg_l23 = 0, dg_bar = 0, dg_top = 0;
-    if constexpr (DIAG == 1) {
-        dg_t0 = stamp();
-        dg_r0 = __builtin_amdgcn_s_memrealtime();
-    }
     if constexpr (DIAG == 2) lt[1] = __builtin_amdgcn_s_memrealtime();
 
     const int xi = 32 * wave + j;      // this lane's feature column in the strip
@@ -387,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // row f - 4 (in the general body both halves compute the same row).  The rows at either end of a work item (the first six or
     // seven, which export to the seam above or see the image top, and at most one row behind the last pair, or the image's
     // bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
-    constexpr bool FASTK = fast_kernel(MODE, PRE, DIAG, ABL);
+    constexpr bool FASTK = fast_kernel(MODE, PRE, DIAG);
     constexpr int FSLOT = 6 * FW;                 // floats per F-tile slot
     int xn[5] = {0, 0, 0, 0, 0};
     bool px_ok = false;
@@ -410,9 +393,9 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // Row offsets that advance by one stride per loop iteration: kept in scalar registers and ADDED to, never
     // re-multiplied (a 64-bit row * stride product per row lands on the vector ALU), so that every global access of the
     // row loop is "scalar base + the lane's 32-bit offset".  o_out: output row f - 3 (the row hp_use() finishes in
-    // iteration f); o_src: Y row min(f + 5, H - 1); o_pl: plane row f (MODE_L12 store) / min(f + 1, H - 1) (MODE_L3 load).
+    // iteration f); o_src: Y row min(f + 5, y_last); o_pl: plane row f (MODE_L12 store) / min(f + 1, H - 1) (MODE_L3 load).
     long o_out = (long)frame * p.dst_frame_pitch + (long)(f_lo - 3 - p.dst_row0) * p.dst_stride;
-    long o_src = (long)(min(f_lo + 5, H - 1) - p.src_row0) * p.src_stride;
+    long o_src = (long)(min(f_lo + 5, y_last) - p.src_row0) * p.src_stride;
     long o_pl = (long)frame * p.pl_frame_pitch + (long)(MODE == MODE_L3 ? min(f_lo + 1, H - 1) : f_lo) * p.pl_stride;
     auto finalize = [&](long o, float acc, bool ok) {
         const float v = acc + p.b3;
@@ -495,8 +478,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         const int y = g - 2 + slot;        // slot > 0 only at the image's last feature row
         const bool rows_ok = (y >= out_lo) && (y < out_hi) && (!FASTK || half == 0);
         finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && rows_ok);
-        if constexpr (!(ABL & 64))
-            if (cs_row0 && rows_ok) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, FASTK ? cl2 : cl);
+        if (cs_row0 && rows_ok) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, FASTK ? cl2 : cl);
     };
     // FAST body, odd rows: output rows f - 3 (lane-half 0, F slot SLOT) and f - 4 (lane-half 1, slot SLOT + 1) together.
     // Both lie inside [out_lo, out_hi) for every row the FAST body runs on.
@@ -554,12 +536,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             hp_use(g, slot);
         }
     };
-    unsigned long long dg_a = 0, dg_b = 0, dg_c = 0, dg_d = 0;
     // One row.  PH < 0: the general body; PH = 0..3: the FAST body for a row with f & 3 == PH (FASTK kernels only).
     auto row = [&](int f, auto ph_tag) {
         constexpr int PH = decltype(ph_tag)::value;
         constexpr bool FAST = PH >= 0;
-        if constexpr (DIAG == 1) dg_a = stamp();
         const int g = f - 1;
         const bool hp = FAST ? (PH & 1) != 0 : (MODE != MODE_L12) && (g >= f_lo);     // g < H-1 inside the loop
         constexpr int SLOT_W = (4 - PH) & 3;              // FAST: the slot feature row f writes
@@ -572,19 +552,14 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             // here would make the compiler wait for the load right away)
             unsigned ynext;
             asm volatile("" : "=v"(ynext));      // (undefined in the lanes that load nothing: no instruction)
-            if constexpr (!(ABL & 8))
-                if (tid < YP) ynext = scalar_base(srcf + o_src)[lane_off((unsigned)ycol)];       // Y row min(f + 5, H - 1)
-            if (f + 5 < H - 1) o_src += p.src_stride;
+            if (tid < YP) ynext = scalar_base(srcf + o_src)[lane_off((unsigned)ycol)];       // Y row min(f + 5, y_last)
+            if (f + 5 < y_last) o_src += p.src_stride;
 
             // ---------------- layer 1: 82 MFMA ------------------------------
             const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
             const float *ybN = yb + half;                    // taps 2s | 2s+1 in one row
             const float *ybW = yb + (half ? YP - 8 : 0);     // tap 2s = (ki,8), tap 2s+1 = (ki+1,0)
-            float abl_b = 1.0f;
-            if constexpr (ABL & 16) asm volatile("" : "+v"(abl_b));
-            f32x2 abl_d[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
             auto ldb = [&](int s) -> float {
-                if constexpr (ABL & 16) return abl_b;
                 const int ki = (2 * s) / 9, kj = (2 * s) % 9;
                 if (s == 40) return half ? 1.0f : yb[8 * YP + 8];   // tap 80 | bias tap
                 if (kj == 8) return ybW[ki * YP + kj];
@@ -599,12 +574,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int s = 0; s < PF; ++s) bq[s] = ldb(s);
 #pragma unroll
                 for (int s = 0; s < 41; ++s) {
-                    if constexpr (ABL & 32) {          // timing experiment: half as many B-operand reads (odd k-steps reuse the even one's)
-                        if (s + PF < 41) bq[s + PF] = ((s + PF) & 1) ? bq[s + PF - 1] : ldb(s + PF);
-                    } else {
-                        if (s + PF < 41) bq[s + PF] = ldb(s + PF);
-                    }
-                    if constexpr (PB && MODE != MODE_L12 && !(ABL & 2) && !(ABL & 128)) {
+                    if (s + PF < 41) bq[s + PF] = ldb(s + PF);
+                    if constexpr (PB && MODE != MODE_L12) {
                         if constexpr (FAST) {
                             if (s == 2) hp2_load(SLOT_R);
                             if (s == 8) hp2_use(f, SLOT_R);
@@ -613,43 +584,23 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                             if (s == 8) hp_use(g, 0);
                         }
                     }
-                    if constexpr ((ABL & 1024) != 0) {   // timing experiment (with 256): the 12 chain adds + 3 F-tile writes inside the layer-1 stream
-                        if (s == 14) {
-                            float *fo = ftile(f, 0) + 3 * half * FW + xi;
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                fo[c * FW] = R[3][c] + bq[s];
-                                R[3][c] = R[2][c] + bq[s + 1];
-                                R[2][c] = R[1][c] + bq[s + 2];
-                                R[1][c] = R[0][c] + bq[s];
-                                R[0][c] = bq[s + 1];
-                            }
-                        }
-                    }
                     a0 = MFMA(w1f[0][s], bq[s], a0);
-                    if constexpr (ABL & 512) {         // timing experiment: the 24 ReLU instructions as single, independent ones between the MFMAs
-                        if (s >= 8 && s < 32) asm volatile("v_pk_mul_f32 %0, %0, %1 clamp" : "+v"(abl_d[s & 3]) : "s"(ones));
-                    }
                     a1 = MFMA(w1f[1][s], bq[s], a1);
                     // keep this k-step's LDS traffic / horizontal-sum slice where it is
                     __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if constexpr (DIAG == 1) dg_b = stamp();
             if constexpr (FAST) {
                 layer1(std::integral_constant<bool, (PH & 1) != 0>{});
             } else {
                 if (hp) layer1(std::true_type{});
                 else layer1(std::false_type{});
             }
-            if constexpr (DIAG == 1) dg_c = stamp();
             // ReLU in bulk BEFORE the dependent layer-2 chain: a VALU instruction between two
             // dependent MFMAs breaks their back-to-back issue (~64 -> ~81 cycles per MFMA,
             // tools/mfma_probe.hip), 32 of them up front cost ~140 cycles once.
-            if constexpr (!(ABL & 4)) {
-                relu_pairs(a0, ones);
-                relu_pairs(a1, ones);
-            }
+            relu_pairs(a0, ones);
+            relu_pairs(a1, ones);
             __builtin_amdgcn_sched_barrier(0);
 
             // ---------------- layer 2: 32 MFMA, one back-to-back chain that starts from the bias ------------
@@ -659,19 +610,16 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2 = MFMA(w2f[16 + r], a1[r], d2);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!(ABL & 4)) {
-                if constexpr (MODE == MODE_L12) {
+            if constexpr (MODE == MODE_L12) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) d2[r] = relu(d2[r]);
-                } else {
-                    relu_pairs(d2, ones);
-                }
+                for (int r = 0; r < 16; ++r) d2[r] = relu(d2[r]);
+            } else {
+                relu_pairs(d2, ones);
             }
             __builtin_amdgcn_sched_barrier(0);
 
             asm volatile("" : "+v"(ynext));
-            if constexpr (!(ABL & 8))
-                if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
+            if (tid < YP) stage_y(f + 5, (uint8_t)ynext);
 
             if constexpr (MODE == MODE_L12) {
                 // register r / half h = channel 2r+h of pixel gx: 128-B runs per plane
@@ -710,9 +658,7 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
                 for (int r = 0; r < 16; ++r) t = MFMA(w3f[r], d2[r], t);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((ABL & 2) || (ABL & 256)) {
-                asm volatile("" ::"v"(t));
-            } else if constexpr (FAST) {
+            if constexpr (FAST) {
                 float *fo = fbuf + SLOT_W * FSLOT + 3 * half * FW + xi;
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
@@ -730,18 +676,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             }
         }
 
-        if constexpr (DIAG == 1) dg_d = stamp();
         // (nothing moves across the row barrier: the unrolled FAST rows would otherwise trade instructions -- and live registers)
         if constexpr (FASTK) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 1)) lds_barrier();
+        lds_barrier();
         if constexpr (FASTK) __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DIAG == 1) {
-            const unsigned long long e = stamp();
-            dg_top += dg_b - dg_a;
-            dg_l1 += dg_c - dg_b;
-            dg_l23 += dg_d - dg_c;
-            dg_bar += e - dg_d;
-        }
         o_out += p.dst_stride;
         if constexpr (MODE == MODE_L3) {
             if (f + 1 < H - 1) o_pl += p.pl_stride;
@@ -803,23 +741,6 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);
             o[6] = (unsigned long long)strip | ((unsigned long long)ys << 32);
-        }
-    }
-    if constexpr (DIAG == 1) {
-        const unsigned long long t1 = stamp();
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        if (lane == 0) {
-            unsigned long long *o = reinterpret_cast<unsigned long long *>(p.sink + 256) +
-                                    ((long)blockIdx.x * NWAVES + wave) * 8;
-            o[0] = t1 - dg_t0;
-            o[1] = r1 - dg_r0;
-            o[2] = dg_top;
-            o[3] = dg_l1;
-            o[4] = dg_l23;
-            o[5] = dg_bar;
-            o[6] = (unsigned long long)(f_hi - f_lo) | ((dg_r0 & 0xffffffffull) << 32);     // rows | start time
-            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |  // HW_ID
-                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);  // XCC_ID
         }
     }
 }
@@ -1025,17 +946,7 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
     const bool pre = p.pre != nullptr;
     switch (mode) {
     case MODE_FUSED:
-        if (p.tune & 2) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 1>), grid, block, lds, stream, p);
-        else if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
-#ifdef SRCNN_ABLATION_BUILD
-#define ABL_CASE(n) case n: hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, n>), grid, block, lds, stream, p); break;
-        else if ((p.tune >> 8) & 2047) {
-            switch ((p.tune >> 8) & 2047) {
-                ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(6) ABL_CASE(7) ABL_CASE(15) ABL_CASE(31) ABL_CASE(32) ABL_CASE(38) ABL_CASE(64) ABL_CASE(128) ABL_CASE(256) ABL_CASE(192) ABL_CASE(516) ABL_CASE(1280)
-            default: return hipErrorInvalidValue;
-            }
-        }
-#endif
+        if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
         else if (pre) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false>), grid, block, lds, stream, p);
         break;

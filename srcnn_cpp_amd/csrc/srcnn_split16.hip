@@ -160,8 +160,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
     // are never read) so staging needs no predicate, and rows are staged two ahead.
     const uint8_t *srcf = p.src + (long)frame * p.src_frame_pitch;
     const int ycol = clampi16(gx0 - 4 + tid, 0, W - 1);
+    // (rows beyond f_hi + 3 feed no feature row of this block: the read stays inside the rows the caller must provide,
+    // [row_begin - 6, row_end + 6) for a row stripe -- include/srcnn_amd.h, srcnn_forward_y_rows_dev)
+    const int y_last = min(H - 1, f_hi + 3);
     auto load_y = [&](int r) -> uint8_t {
-        const int rr = clampi16(r, 0, H - 1) - p.src_row0;
+        const int rr = clampi16(r, 0, y_last) - p.src_row0;
         return srcf[(long)rr * p.src_stride + ycol];
     };
     const int c1col = tid == 0 ? SP_RS - 1 : tid - 1;                     // copy 1 holds column c at element c-1
