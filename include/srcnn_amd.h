@@ -118,6 +118,27 @@ int srcnn_conv99x11(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
                     const float *kernel99 /*[64][9][9]*/, const float *bias99 /*[64]*/,
                     const float *kernel11 /*[32][64]*/, const float *bias11 /*[32]*/);
 
+/* The same two call sites (src/srcnn.cpp:609, :627) with the 32-plane map kept in DEVICE memory between them, so that
+ * its 128 B/pixel (1.06 GB at 3840x2160) never cross PCIe: Convolution99x11 with a host u8 plane in and device planes
+ * out, Convolution55 with device planes in and a host u8 plane out.  d_planes is ONE device allocation on the context's
+ * GPU, plane k at d_planes + k*plane_pitch (elements); srcnn_dev_alloc below, or the caller's own hipMalloc.
+ * srcnn_conv99x11_to_dev returns with its kernel queued on the context's stream; srcnn_conv55_from_dev (ordered behind it
+ * on that stream) returns when dst is complete.  include/srcnn_amd.hpp's DevicePlane<float> overloads call these. */
+int srcnn_conv99x11_to_dev(srcnn_ctx *ctx, const uint8_t *src, size_t src_stride,
+                           float *d_planes, size_t plane_stride, size_t plane_pitch, int width, int height,
+                           const float *kernel99 /*[64][9][9]*/, const float *bias99 /*[64]*/,
+                           const float *kernel11 /*[32][64]*/, const float *bias11 /*[32]*/);
+int srcnn_conv55_from_dev(srcnn_ctx *ctx, const float *d_planes, size_t plane_stride, size_t plane_pitch,
+                          uint8_t *dst, size_t dst_stride, int width, int height,
+                          const float *kernel /*[32][5][5]*/, float bias);
+
+/* Device memory on the context's GPU for hosts that include no HIP header (the C++ adapters' DevicePlane): allocate,
+ * free (waits for the context's stream), and synchronous copies ordered behind the context's stream. */
+int srcnn_dev_alloc(srcnn_ctx *ctx, size_t bytes, void **out);
+int srcnn_dev_free(srcnn_ctx *ctx, void *d_ptr);
+int srcnn_dev_download(srcnn_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int srcnn_dev_upload(srcnn_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+
 /* ---- whole path: what src/srcnn.cpp:602-627 does with the above ------------ */
 
 /* Upload the model once (any later call may replace it). */

@@ -25,6 +25,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -142,6 +143,99 @@ inline void Convolution99x11(MatU8 &src, std::vector<MatF32> &dst,
     s.check(srcnn_conv99x11(s.get(), detail::ptr<const std::uint8_t>(src), detail::stride<std::uint8_t>(src),
                             planes, detail::stride<float>(dst[0]), src.cols, src.rows,   // dims from src: :262-263
                             &kernel99[0][0][0], bias99, &kernel11[0][0], bias11));
+}
+
+// ---- the same two call sites with the 32-plane map kept on the GPU --------------------------------------------
+// The reference allocates 32 CV_32F Mats (src/srcnn.cpp:602-607), fills them at :609 and consumes them at :627: with host
+// Mats that is 2 x 128 B/pixel over PCIe (42 ms per 3840x2160 plane, 40 x the kernels).  A maintainer who changes ONLY the
+// element type of that vector keeps the text of :609 and :627 and never moves the map off the device:
+//
+//     std::vector<srcnn::DevicePlane<float>> pImgConv2 = srcnn::DevicePlanes<float>(CONV2_FILTERS, pImg[0].cols, pImg[0].rows);
+//     Convolution99x11(pImg[0], pImgConv2, conv1_Weights, conv1_biases, conv2_Weights, conv2_biases);      // :609 unchanged
+//     Convolution55(pImgConv2, pImgConv3, conv3_Weights, conv3_biases);                                     // :627 unchanged
+//
+// DevicePlane has cv::Mat's field names (rows, cols, step, data) but `data` is a DEVICE address; the planes of one
+// DevicePlanes() call share one allocation on the calling thread's Session (plane k at k * rows * cols elements), which
+// is freed when the last of them goes away -- before its Session does.
+template <class T>
+struct DevicePlane {
+    int rows = 0, cols = 0;
+    std::size_t step = 0;            // bytes per row
+    unsigned char *data = nullptr;   // DEVICE memory
+    std::shared_ptr<void> owner;     // the allocation this plane lives in
+    srcnn_ctx *ctx = nullptr;        // the context whose GPU holds it
+    bool empty() const { return data == nullptr; }
+    // a host copy, for inspection (synchronises the context's stream)
+    Plane<T> download() const
+    {
+        Plane<T> h(cols, rows);
+        if (srcnn_dev_download(ctx, h.data, data, sizeof(T) * static_cast<std::size_t>(rows) * cols) != SRCNN_OK)
+            throw Error(SRCNN_ERR_HIP, srcnn_last_error(ctx));
+        return h;
+    }
+};
+
+template <class T>
+inline std::vector<DevicePlane<T>> DevicePlanes(int n, int cols, int rows, Session &s = Session::thread_default())
+{
+    if (n <= 0 || cols <= 0 || rows <= 0) throw Error(SRCNN_ERR_INVALID, "DevicePlanes: bad size");
+    const std::size_t pitch = static_cast<std::size_t>(rows) * cols;
+    void *p = nullptr;
+    s.check(srcnn_dev_alloc(s.get(), sizeof(T) * pitch * n, &p));
+    srcnn_ctx *ctx = s.get();
+    std::shared_ptr<void> owner(p, [ctx](void *q) { (void)srcnn_dev_free(ctx, q); });
+    std::vector<DevicePlane<T>> v(static_cast<std::size_t>(n));
+    for (int k = 0; k < n; ++k) {
+        v[k].rows = rows;
+        v[k].cols = cols;
+        v[k].step = sizeof(T) * static_cast<std::size_t>(cols);
+        v[k].data = static_cast<unsigned char *>(p) + sizeof(T) * pitch * k;
+        v[k].owner = owner;
+        v[k].ctx = ctx;
+    }
+    return v;
+}
+
+namespace detail {
+// plane k of the vector at data[0] + k * pitch: the layout the device kernels address (one scalar base per plane pair)
+template <class T>
+inline std::size_t uniform_pitch(const std::vector<DevicePlane<T>> &v, const char *who)
+{
+    const std::size_t pitch = v.size() > 1 ? static_cast<std::size_t>(v[1].data - v[0].data) / sizeof(T)
+                                           : static_cast<std::size_t>(v[0].rows) * (v[0].step / sizeof(T));
+    for (std::size_t k = 0; k < v.size(); ++k)
+        if (!v[k].data || v[k].rows != v[0].rows || v[k].cols != v[0].cols || v[k].step != v[0].step || v[k].ctx != v[0].ctx ||
+            v[k].data != v[0].data + sizeof(T) * pitch * k)
+            throw Error(SRCNN_ERR_INVALID, std::string(who) + ": the device planes must come from one DevicePlanes() call");
+    return pitch;
+}
+}  // namespace detail
+
+template <class MatU8>
+inline void Convolution99x11(MatU8 &src, std::vector<DevicePlane<float>> &dst,
+                             const float kernel99[SRCNN_CONV1_FILTERS][9][9], const float bias99[SRCNN_CONV1_FILTERS],
+                             const float kernel11[SRCNN_CONV2_FILTERS][SRCNN_CONV1_FILTERS],
+                             const float bias11[SRCNN_CONV2_FILTERS])
+{
+    if (dst.size() != SRCNN_CONV2_FILTERS) throw Error(SRCNN_ERR_INVALID, "Convolution99x11: need 32 planes");
+    const std::size_t pitch = detail::uniform_pitch(dst, "Convolution99x11");
+    srcnn_ctx *c = dst[0].ctx;
+    const int rc = srcnn_conv99x11_to_dev(c, detail::ptr<const std::uint8_t>(src), detail::stride<std::uint8_t>(src),
+                                          detail::ptr<float>(dst[0]), detail::stride<float>(dst[0]), pitch, src.cols, src.rows,
+                                          &kernel99[0][0][0], bias99, &kernel11[0][0], bias11);      // dims from src: :262-263
+    if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(c));
+}
+
+template <class MatU8>
+inline void Convolution55(std::vector<DevicePlane<float>> &src, MatU8 &dst, const float kernel[32][5][5], float bias)
+{
+    if (src.size() != SRCNN_CONV2_FILTERS) throw Error(SRCNN_ERR_INVALID, "Convolution55: need 32 planes");
+    const std::size_t pitch = detail::uniform_pitch(src, "Convolution55");
+    srcnn_ctx *c = src[0].ctx;
+    const int rc = srcnn_conv55_from_dev(c, detail::ptr<const float>(src[0]), detail::stride<float>(src[0]), pitch,
+                                         detail::ptr<std::uint8_t>(dst), detail::stride<std::uint8_t>(dst), dst.cols, dst.rows,
+                                         &kernel[0][0][0], bias);                                     // dims from dst: :191-192
+    if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(c));
 }
 
 // The whole conv path of src/srcnn.cpp:602-627 in one fused kernel.

@@ -106,6 +106,12 @@ def load_library() -> C.CDLL:
         "srcnn_forward_y_unfused_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
         "srcnn_conv99x11_dev": ([vp, vp, sz, vp, sz, sz, i, i], i),
         "srcnn_conv55_dev": ([vp, vp, sz, sz, vp, sz, i, i, vp], i),
+        "srcnn_conv99x11_to_dev": ([vp, _u8p, sz, vp, sz, sz, i, i, _f32p, _f32p, _f32p, _f32p], i),
+        "srcnn_conv55_from_dev": ([vp, vp, sz, sz, _u8p, sz, i, i, _f32p, C.c_float], i),
+        "srcnn_dev_alloc": ([vp, sz, C.POINTER(vp)], i),
+        "srcnn_dev_free": ([vp, vp], i),
+        "srcnn_dev_download": ([vp, vp, vp, sz], i),
+        "srcnn_dev_upload": ([vp, vp, vp, sz], i),
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
@@ -132,7 +138,8 @@ ABI_SYMBOLS = (
     "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_frames",
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
-    "srcnn_conv55_dev", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
@@ -289,6 +296,36 @@ class Context:
         _same_shape("dst planes", shape, src.shape)
         self._check(self._lib.srcnn_conv99x11(self._h, src.ctypes.data_as(_u8p), ss, arr, ds, w, h,
                                               _fp(k99), _fp(b99), _fp(k11), _fp(b11)))
+
+    # the two reference calls with the 32-plane map kept in device memory between them (include/srcnn_amd.h)
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.srcnn_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, d_ptr: int):
+        self._check(self._lib.srcnn_dev_free(self._h, d_ptr))
+
+    def dev_download(self, dst: np.ndarray, d_src: int):
+        if not (isinstance(dst, np.ndarray) and dst.flags.c_contiguous and dst.flags.writeable):
+            raise ValueError("dst: expected a writeable C-contiguous numpy array")
+        self._check(self._lib.srcnn_dev_download(self._h, dst.ctypes.data_as(C.c_void_p), d_src, dst.nbytes))
+        return dst
+
+    def conv99x11_to_dev(self, src, d_planes, plane_stride, plane_pitch, k99, b99, k11, b11):
+        src, ss = _plane(src, np.uint8, "src")
+        k99, b99 = _wt(k99, 5184, "kernel99"), _wt(b99, 64, "bias99")
+        k11, b11 = _wt(k11, 2048, "kernel11"), _wt(b11, 32, "bias11")
+        h, w = src.shape
+        self._check(self._lib.srcnn_conv99x11_to_dev(self._h, src.ctypes.data_as(_u8p), ss, d_planes, plane_stride, plane_pitch,
+                                                     w, h, _fp(k99), _fp(b99), _fp(k11), _fp(b11)))
+
+    def conv55_from_dev(self, d_planes, plane_stride, plane_pitch, dst, kernel, bias):
+        dst, ds = _plane(dst, np.uint8, "dst", True)
+        k = _wt(kernel, 800, "kernel")
+        h, w = dst.shape
+        self._check(self._lib.srcnn_conv55_from_dev(self._h, d_planes, plane_stride, plane_pitch, dst.ctypes.data_as(_u8p), ds,
+                                                    w, h, _fp(k), float(bias)))
 
     def forward_y(self, src, dst=None, preclamp=None):
         """Fused Convolution99x11 + Convolution55 (needs set_weights)."""

@@ -41,6 +41,17 @@ UNITS = [
 ]
 
 
+def kernel_sources_fingerprint() -> str:
+    """sha256 over the sources that decide what the conv-path kernels do and how they are launched.  The rocprofv3 --pmc
+    figures bench.py quotes (profiles/pmc_traffic.json) carry the fingerprint they were taken with; a line never quotes
+    counters of a different kernel build (the GPU box holds no .git, so a commit id cannot serve)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("srcnn_mfma.hip", "srcnn_split16.hip", "srcnn_kernels.h", "srcnn_api.cpp"):
+        h.update((CSRC / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(exe).exists():

@@ -14,7 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -26,6 +30,77 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+};
+
+// Persistent host threads of the several-GPUs entry points (srcnn_forward_y_striped*, srcnn_forward_y_frames_multi):
+// one worker per context beyond the first, created on first use and parked on a condition variable between calls.
+// Spawning and joining n_ctx - 1 std::threads PER STEP cost tens of microseconds next to 0.47 ms of kernel per rank for
+// a 7680x4320 plane on 8 GPUs.  Owned by the first context of the set (a context belongs to one host thread at a time,
+// include/srcnn_amd.h), destroyed with it.
+class WorkerPool {
+    struct Worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<int()> task;
+        bool has_task = false, done = false, stop = false;
+        int rc = 0;
+    };
+    std::vector<std::unique_ptr<Worker>> workers_;
+
+    static void loop(Worker *w)
+    {
+        std::unique_lock<std::mutex> lk(w->m);
+        for (;;) {
+            w->cv.wait(lk, [w] { return w->has_task || w->stop; });
+            if (w->stop) return;
+            std::function<int()> t = std::move(w->task);
+            w->has_task = false;
+            lk.unlock();
+            const int rc = t();
+            lk.lock();
+            w->rc = rc;
+            w->done = true;
+            w->cv.notify_all();
+        }
+    }
+
+public:
+    WorkerPool() = default;
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    ~WorkerPool()
+    {
+        for (auto &w : workers_) {
+            { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+    // fn(k) for k = 0 .. n - 1: k = 0 on the calling thread, the others on the parked workers; returns the first non-zero code
+    template <typename Fn>
+    int run(int n, Fn fn)
+    {
+        while ((int)workers_.size() < n - 1) {
+            workers_.emplace_back(new Worker());
+            Worker *w = workers_.back().get();
+            w->th = std::thread(loop, w);
+        }
+        for (int k = 1; k < n; ++k) {
+            Worker *w = workers_[(size_t)k - 1].get();
+            { std::lock_guard<std::mutex> lk(w->m); w->task = [&fn, k] { return fn(k); }; w->has_task = true; w->done = false; }
+            w->cv.notify_all();
+        }
+        int first = fn(0);
+        for (int k = 1; k < n; ++k) {
+            Worker *w = workers_[(size_t)k - 1].get();
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [w] { return w->done; });
+            if (!first && w->rc) first = w->rc;
+        }
+        return first;
+    }
+    int size() const { return (int)workers_.size(); }
 };
 
 }  // namespace
@@ -89,6 +164,7 @@ struct srcnn_ctx {
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
     size_t pin_cap = 0;
+    std::unique_ptr<WorkerPool> pool;      // host threads of the several-GPUs calls this context leads (WorkerPool)
 };
 
 namespace {
@@ -1297,6 +1373,7 @@ int srcnn_create(srcnn_ctx **out, int device)
 void srcnn_destroy(srcnn_ctx *c)
 {
     if (!c) return;
+    c->pool.reset();                       // parks no more workers: joins them
     DeviceScope dev_scope_(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();          // work on any stream the context was given may still use its buffers
@@ -1795,6 +1872,38 @@ int srcnn_forward_y(srcnn_ctx *c, const uint8_t *src, size_t src_stride, uint8_t
     return SRCNN_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// The per-call tables of the reference surface (src/srcnn.cpp:609, :627: the same const arrays on every call).
+// Layers 1-2 of the model are replaced, layer 3 of any loaded model is kept (and the other way round for layer 3);
+// tables equal to the uploaded ones are not packed or uploaded again.
+int use_layers12(srcnn_ctx *c, const float *kernel99, const float *bias99, const float *kernel11, const float *bias11)
+{
+    const float *hr = c->host_raw.data();
+    const bool same = c->has_l12 && !std::memcmp(hr, bias99, 64 * 4) && !std::memcmp(hr + 64, kernel99, 5184 * 4) &&
+                      !std::memcmp(hr + 5248, bias11, 32 * 4) && !std::memcmp(hr + 5280, kernel11, 2048 * 4);
+    if (same) return SRCNN_OK;
+    const std::vector<float> w3(hr + 7329, hr + 8129);      // upload_weights rewrites host_raw
+    const int rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), c->b3);
+    if (rc == SRCNN_OK) c->has_l12 = true;
+    return rc;
+}
+int use_layer3(srcnn_ctx *c, const float *kernel, float bias)
+{
+    const float *hr = c->host_raw.data();
+    if (c->has_l3 && hr[7328] == bias && !std::memcmp(hr + 7329, kernel, 800 * 4)) return SRCNN_OK;
+    const std::vector<float> raw(c->host_raw);               // upload_weights rewrites host_raw
+    const int rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias);
+    if (rc == SRCNN_OK) c->has_l3 = true;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
 int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *const *dst, size_t dst_stride,
                     int width, int height, const float *kernel99, const float *bias99, const float *kernel11,
                     const float *bias11)
@@ -1806,16 +1915,7 @@ int srcnn_conv99x11(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *
         return fail(c, SRCNN_ERR_INVALID, "conv99x11: bad arguments");
     for (int k = 0; k < 32; ++k)
         if (!dst[k]) return fail(c, SRCNN_ERR_INVALID, "conv99x11: null output plane %d", k);
-    // Layers 1-2 of the model are replaced, layer 3 of any loaded model is kept.  The reference passes the same
-    // const tables on every call (src/srcnn.cpp:609): tables equal to the uploaded ones are not packed again.
-    const float *hr = c->host_raw.data();
-    const bool same = c->has_l12 && !std::memcmp(hr, bias99, 64 * 4) && !std::memcmp(hr + 64, kernel99, 5184 * 4) &&
-                      !std::memcmp(hr + 5248, bias11, 32 * 4) && !std::memcmp(hr + 5280, kernel11, 2048 * 4);
-    if (!same) {
-        const std::vector<float> w3(hr + 7329, hr + 8129);      // upload_weights rewrites host_raw
-        if ((rc = upload_weights(c, kernel99, bias99, kernel11, bias11, w3.data(), c->b3))) return rc;
-        c->has_l12 = true;
-    }
+    if ((rc = use_layers12(c, kernel99, bias99, kernel11, bias11))) return rc;
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->in_u8, n))) return rc;
     if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
@@ -1836,15 +1936,7 @@ int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8
         return fail(c, SRCNN_ERR_INVALID, "conv55: bad arguments");
     for (int k = 0; k < 32; ++k)
         if (!src[k]) return fail(c, SRCNN_ERR_INVALID, "conv55: null input plane %d", k);
-    // layer 3 of the model is replaced; layers 1-2 of any loaded model are kept (src/srcnn.cpp:627)
-    const float *hr = c->host_raw.data();
-    const bool same = c->has_l3 && hr[7328] == bias && !std::memcmp(hr + 7329, kernel, 800 * 4);
-    if (!same) {
-        const std::vector<float> raw(c->host_raw);               // upload_weights rewrites host_raw
-        if ((rc = upload_weights(c, raw.data() + 64, raw.data(), raw.data() + 5280, raw.data() + 5248, kernel, bias)))
-            return rc;
-        c->has_l3 = true;
-    }
+    if ((rc = use_layer3(c, kernel, bias))) return rc;      // src/srcnn.cpp:627
     const size_t n = (size_t)width * height;
     if ((rc = reserve(c, c->planes, n * 32 * 4))) return rc;
     if ((rc = reserve(c, c->out_u8, n))) return rc;
@@ -1855,6 +1947,80 @@ int srcnn_conv55(srcnn_ctx *c, const float *const *src, size_t src_stride, uint8
     HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->out_u8.p, width, width, height, hipMemcpyDeviceToHost,
                                 c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+/* The reference's two call sites (src/srcnn.cpp:609, :627) with the 32-plane map kept in DEVICE memory between them:
+ * host u8 plane in -> device planes, device planes -> host u8 plane out.  128 B/pixel never cross PCIe. */
+int srcnn_conv99x11_to_dev(srcnn_ctx *c, const uint8_t *src, size_t src_stride, float *d_planes, size_t plane_stride,
+                           size_t plane_pitch, int width, int height, const float *kernel99, const float *bias99,
+                           const float *kernel11, const float *bias11)
+{
+    BIND(c);
+    int rc = SRCNN_OK;
+    if (bad_plane(src, src_stride, width, height) || !kernel99 || !bias99 || !kernel11 || !bias11)
+        return fail(c, SRCNN_ERR_INVALID, "conv99x11_to_dev: bad arguments");
+    if ((rc = use_layers12(c, kernel99, bias99, kernel11, bias11))) return rc;
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->in_u8, n))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(c->in_u8.p, width, src, src_stride, width, height, hipMemcpyHostToDevice, c->stream));
+    // asynchronous from here on: srcnn_conv55_from_dev (same context, same stream) or srcnn_synchronize orders behind it
+    return srcnn_conv99x11_dev(c, static_cast<uint8_t *>(c->in_u8.p), width, d_planes, plane_stride, plane_pitch, width, height);
+}
+
+int srcnn_conv55_from_dev(srcnn_ctx *c, const float *d_planes, size_t plane_stride, size_t plane_pitch, uint8_t *dst,
+                          size_t dst_stride, int width, int height, const float *kernel, float bias)
+{
+    BIND(c);
+    int rc = SRCNN_OK;
+    if (bad_plane(dst, dst_stride, width, height) || !kernel)
+        return fail(c, SRCNN_ERR_INVALID, "conv55_from_dev: bad arguments");
+    if ((rc = use_layer3(c, kernel, bias))) return rc;
+    const size_t n = (size_t)width * height;
+    if ((rc = reserve(c, c->out_u8, n))) return rc;
+    if ((rc = srcnn_conv55_dev(c, d_planes, plane_stride, plane_pitch, static_cast<uint8_t *>(c->out_u8.p), width, width, height,
+                               nullptr)))
+        return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(dst, dst_stride, c->out_u8.p, width, width, height, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SRCNN_OK;
+}
+
+/* Device memory for callers that hold no HIP headers (include/srcnn_amd.hpp's DevicePlane): plain allocations on the
+ * context's GPU, freed by the caller; copies are synchronous and ordered behind the context's stream. */
+int srcnn_dev_alloc(srcnn_ctx *c, size_t bytes, void **out)
+{
+    BIND(c);
+    if (!out || bytes == 0) return fail(c, SRCNN_ERR_INVALID, "dev_alloc: bad arguments");
+    *out = nullptr;
+    HIP_TRY(c, hipMalloc(out, bytes));
+    return SRCNN_OK;
+}
+
+int srcnn_dev_free(srcnn_ctx *c, void *p)
+{
+    BIND(c);
+    if (!p) return SRCNN_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // queued work may still use it
+    HIP_TRY(c, hipFree(p));
+    return SRCNN_OK;
+}
+
+int srcnn_dev_download(srcnn_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+    BIND(c);
+    if (!dst || !d_src) return fail(c, SRCNN_ERR_INVALID, "dev_download: null pointer");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SRCNN_OK;
+}
+
+int srcnn_dev_upload(srcnn_ctx *c, void *d_dst, const void *src, size_t bytes)
+{
+    BIND(c);
+    if (!d_dst || !src) return fail(c, SRCNN_ERR_INVALID, "dev_upload: null pointer");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return SRCNN_OK;
 }
 
@@ -2150,17 +2316,14 @@ int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const 
     return SRCNN_OK;
 }
 
+// fn(k) for every context of the set, context k > 0 on the k-th persistent worker thread of ctxs[0]'s pool
 template <typename Fn>
-int run_per_context(int n_ctx, Fn fn)
+int run_per_context(srcnn_ctx *const *ctxs, int n_ctx, Fn fn)
 {
-    std::vector<int> rcs((size_t)n_ctx, SRCNN_OK);
-    std::vector<std::thread> pool;
-    for (int k = 1; k < n_ctx; ++k) pool.emplace_back([&rcs, &fn, k] { rcs[(size_t)k] = fn(k); });
-    rcs[0] = fn(0);
-    for (auto &t : pool) t.join();
-    for (int rc : rcs)
-        if (rc) return rc;
-    return SRCNN_OK;
+    if (n_ctx == 1) return fn(0);
+    if (!ctxs[0]->pool) ctxs[0]->pool.reset(new (std::nothrow) WorkerPool());
+    if (!ctxs[0]->pool) return fail(ctxs[0], SRCNN_ERR_NOMEM, "worker pool");
+    return ctxs[0]->pool->run(n_ctx, fn);
 }
 
 }  // namespace
@@ -2181,7 +2344,7 @@ int srcnn_forward_y_striped_dev(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t
         if (!d_stripes[k] || !d_out[k]) return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_dev: null stripe %d", k);
         if (ctxs[k]->mode == SRCNN_MODE_EXACT) return fail(ctxs[k], SRCNN_ERR_STATE, "row stripes are MFMA-mode only");
     }
-    return run_per_context(n_ctx, [&](int k) {
+    return run_per_context(ctxs, n_ctx, [&](int k) {
         return striped_step(ctxs, n_ctx, k, d_stripes, stripe_stride, d_out, out_stride, width, height);
     });
 }
@@ -2198,7 +2361,7 @@ int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *sr
     std::vector<const uint8_t *> d_in((size_t)n_ctx);
     std::vector<uint8_t *> d_res((size_t)n_ctx);
     // phase 1: every device receives ITS rows only (the halo rows then travel device to device)
-    rc = run_per_context(n_ctx, [&](int k) -> int {
+    rc = run_per_context(ctxs, n_ctx, [&](int k) -> int {
         srcnn_ctx *c = ctxs[k];
         BIND(c);
         int r, r0, r1;
@@ -2215,7 +2378,7 @@ int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *sr
     });
     if (rc) return rc;
     // phase 2: halo copies + interior rows + edge bands, then each device returns its rows
-    return run_per_context(n_ctx, [&](int k) -> int {
+    return run_per_context(ctxs, n_ctx, [&](int k) -> int {
         srcnn_ctx *c = ctxs[k];
         BIND(c);
         int r, r0, r1;
@@ -2237,7 +2400,7 @@ int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx, const uint8_
         dst_stride < (size_t)width)
         return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_frames_multi: bad arguments");
     // contiguous frame ranges, one host thread per context, no collective: frames are independent
-    return run_per_context(n_ctx, [&](int k) -> int {
+    return run_per_context(ctxs, n_ctx, [&](int k) -> int {
         int f0, f1;
         srcnn_stripe_rows(n_frames, n_ctx, k, &f0, &f1);
         if (f1 == f0) return SRCNN_OK;

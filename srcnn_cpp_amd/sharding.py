@@ -194,70 +194,119 @@ def band_plan(height: int, world: int, rank: int):
     return (i0, i1), ((r0, r0 + HALO_ROWS) if has_top else None), ((r1 - HALO_ROWS, r1) if has_bot else None)
 
 
-def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,
-                           group=None, overlap: bool = True, via_host: bool = False):
-    """One row-striped step of ONE plane, asynchronous on the caller's stream.
+class StripeStep:
+    """The row-striped step of ONE plane on this rank, with everything that does not change from step to step
+    built ONCE: band buffers ([6 halo rows | 12 own rows], [12 own rows | 6 halo rows]), host staging of the
+    halo rows (``via_host``), the send views and the point-to-point op list.  ``step()`` then only posts the
+    exchange, launches, copies 2 x 12 rows on the device and waits -- no allocation, no ``.contiguous()`` copy,
+    no tensor construction per step (at 8 GPUs a 7680x4320 step is 0.47 ms of kernel per rank).
 
-    stripe / out : uint8 tensors [r1-r0, W], this rank's rows of the input / output plane.
-    overlap      : post the 6-row point-to-point exchange, launch the INTERIOR rows (which need no halo)
-                   while it is in flight, then the two 6-row edge bands from [halo | 12 own rows] buffers;
-                   otherwise exchange first and launch once (``forward_striped``).  Same bytes either way:
-                   any partition of the rows computes the same plane (tests/test_sharding_gloo.py).
+    stripe / out : uint8 tensors [r1-r0, W], this rank's rows of the input / output plane; the SAME tensors
+                   every step (refill ``stripe`` in place for a new plane).  ``stripe`` must be contiguous: its
+                   first / last 6 rows are sent as they lie.
+    overlap      : post the 6-row exchange, launch the INTERIOR rows (which need no halo) while it is in
+                   flight, then the two 6-row edge bands; otherwise (or for stripes thinner than 18 rows)
+                   exchange into a persistent [halo | stripe | halo] buffer and launch once.  Same bytes either
+                   way: any partition of the rows computes the same plane (tests/test_sharding_gloo.py).
     via_host     : stage the halo rows through host memory (gloo group; smoke tests on a shared GPU).
     """
-    import torch
-    import torch.distributed as dist
 
-    r0, r1 = stripe_rows(height, world, rank)
-    plan = band_plan(height, world, rank) if (overlap and world > 1) else None
-    if world == 1:
-        launch_rows(stripe, 0, out, 0, height, 0, height)
-        return out
-    if plan is None:
-        if via_host:
-            ext, s0 = exchange_halo_via_host(stripe, height, world, rank, group)
+    def __init__(self, stripe, out, height: int, world: int, rank: int, launch_rows: Callable, group=None,
+                 overlap: bool = True, via_host: bool = False):
+        import torch
+        import torch.distributed as dist
+
+        self.stripe, self.out, self.height, self.world, self.rank = stripe, out, height, world, rank
+        self.launch_rows, self.group, self.via_host = launch_rows, group, via_host
+        self.r0, self.r1 = stripe_rows(height, world, rank)
+        if stripe.shape[0] != self.r1 - self.r0 or out.shape != stripe.shape:
+            raise ValueError(f"rank {rank}: stripe has {stripe.shape[0]} rows, owns [{self.r0},{self.r1})")
+        if world > 1 and not stripe.is_contiguous():
+            raise ValueError("stripe must be contiguous (its edge rows are sent in place)")
+        if world > 1 and min(b - a for a, b in (stripe_rows(height, world, k) for k in range(world))) < HALO_ROWS:
+            raise ValueError("stripes thinner than the halo: use fewer ranks for this plane")
+        self.plan = band_plan(height, world, rank) if (overlap and world > 1) else None
+        self.ops, self.top_buf, self.bot_buf, self.ext = [], None, None, None
+        self.stage = []                # (device view, host tensor): sends copied out before / receives copied in after
+        if world == 1:
+            return
+        dev, width, rows = stripe.device, stripe.shape[1], self.r1 - self.r0
+        has_top, has_bot = rank > 0, rank < world - 1
+        self.s0, self.s1 = halo_extent(height, self.r0, self.r1)
+        if self.plan is None:          # one launch on [halo | stripe | halo]
+            self.ext = torch.empty((self.s1 - self.s0, width), dtype=stripe.dtype, device=dev)
+            recv_top = self.ext[:HALO_ROWS] if has_top else None
+            recv_bot = self.ext[self.ext.shape[0] - HALO_ROWS:] if has_bot else None
         else:
-            ext, s0 = exchange_halo(stripe, height, world, rank, group)
-        launch_rows(ext, s0, out, r0, height, r0, r1)
+            if has_top:
+                self.top_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
+            if has_bot:
+                self.bot_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
+            recv_top = self.top_buf[:HALO_ROWS] if has_top else None
+            recv_bot = self.bot_buf[2 * HALO_ROWS:] if has_bot else None
+        send_top, send_bot = stripe[:HALO_ROWS], stripe[rows - HALO_ROWS:]
+        self._send_stage, self._recv_stage = [], []
+
+        def endpoint(view, sending):
+            if not via_host:
+                return view
+            host = torch.empty(view.shape, dtype=view.dtype)
+            (self._send_stage if sending else self._recv_stage).append((view, host))
+            return host
+        if has_top:      # rank-1: receive its last rows, send it my first rows
+            self.ops += [dist.P2POp(dist.irecv, endpoint(recv_top, False), rank - 1, group),
+                         dist.P2POp(dist.isend, endpoint(send_top, True), rank - 1, group)]
+        if has_bot:
+            self.ops += [dist.P2POp(dist.isend, endpoint(send_bot, True), rank + 1, group),
+                         dist.P2POp(dist.irecv, endpoint(recv_bot, False), rank + 1, group)]
+
+    def _post(self):
+        import torch.distributed as dist
+        for view, host in self._send_stage:
+            host.copy_(view)
+        return dist.batch_isend_irecv(self.ops)
+
+    def _land(self, reqs):
+        for req in reqs:
+            req.wait()
+        for view, host in self._recv_stage:
+            view.copy_(host)
+
+    def step(self):
+        """One step, asynchronous on the caller's stream (the context must launch on torch's current stream)."""
+        stripe, out, h, r0, r1 = self.stripe, self.out, self.height, self.r0, self.r1
+        if self.world == 1:
+            self.launch_rows(stripe, 0, out, 0, h, 0, h)
+            return out
+        if self.plan is None:
+            reqs = self._post()
+            top_n = r0 - self.s0
+            self.ext[top_n:top_n + (r1 - r0)] = stripe
+            self._land(reqs)
+            self.launch_rows(self.ext, self.s0, out, r0, h, r0, r1)
+            return out
+        (i0, i1), top, bot = self.plan
+        reqs = self._post()
+        self.launch_rows(stripe, r0, out, r0, h, i0, i1)          # overlaps the exchange
+        if top:
+            self.top_buf[HALO_ROWS:] = stripe[:2 * HALO_ROWS]
+        if bot:
+            self.bot_buf[:2 * HALO_ROWS] = stripe[stripe.shape[0] - 2 * HALO_ROWS:]
+        self._land(reqs)
+        if top:
+            self.launch_rows(self.top_buf, r0 - HALO_ROWS, out, r0, h, top[0], top[1])
+        if bot:
+            self.launch_rows(self.bot_buf, r1 - 2 * HALO_ROWS, out, r0, h, bot[0], bot[1])
         return out
-    (i0, i1), top, bot = plan
-    # band inputs on the device: [6 halo rows | first 12 own rows] and [last 12 own rows | 6 halo rows];
-    # only the 6-row halos travel (device to device over RCCL, or through host memory with via_host)
-    dev, width = stripe.device, stripe.shape[1]
-    xdev = "cpu" if via_host else dev
-    ops, keep = [], []
-    top_buf = bot_buf = recv_top = recv_bot = None
-    if top:
-        top_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
-        recv_top = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=xdev) if via_host else top_buf[:HALO_ROWS]
-        send = stripe[:HALO_ROWS].to(xdev).contiguous()
-        keep.append(send)
-        ops += [dist.P2POp(dist.irecv, recv_top, rank - 1, group),
-                dist.P2POp(dist.isend, send, rank - 1, group)]
-    if bot:
-        bot_buf = torch.empty((3 * HALO_ROWS, width), dtype=stripe.dtype, device=dev)
-        recv_bot = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=xdev) if via_host else bot_buf[2 * HALO_ROWS:]
-        send = stripe[-HALO_ROWS:].to(xdev).contiguous()
-        keep.append(send)
-        ops += [dist.P2POp(dist.isend, send, rank + 1, group),
-                dist.P2POp(dist.irecv, recv_bot, rank + 1, group)]
-    reqs = dist.batch_isend_irecv(ops)
-    launch_rows(stripe, r0, out, r0, height, i0, i1)          # overlaps the exchange
-    if top:
-        top_buf[HALO_ROWS:] = stripe[:2 * HALO_ROWS]
-    if bot:
-        bot_buf[:2 * HALO_ROWS] = stripe[-2 * HALO_ROWS:]
-    for req in reqs:
-        req.wait()
-    if top:
-        if via_host:
-            top_buf[:HALO_ROWS] = recv_top.to(dev)
-        launch_rows(top_buf, r0 - HALO_ROWS, out, r0, height, top[0], top[1])
-    if bot:
-        if via_host:
-            bot_buf[2 * HALO_ROWS:] = recv_bot.to(dev)
-        launch_rows(bot_buf, r1 - 2 * HALO_ROWS, out, r0, height, bot[0], bot[1])
-    return out
+
+    __call__ = step
+
+
+def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,
+                           group=None, overlap: bool = True, via_host: bool = False):
+    """One row-striped step of ONE plane (a ``StripeStep`` built and run once; callers that step repeatedly keep
+    the ``StripeStep``).  Returns ``out``."""
+    return StripeStep(stripe, out, height, world, rank, launch_rows, group=group, overlap=overlap, via_host=via_host).step()
 
 
 def gather_stripes(out, height: int, world: int, rank: int, dst: int = 0, group=None):

@@ -119,3 +119,59 @@ def test_batch_launch_forms_equal_single_plane(gpu_ctx, weights_blob, n_frames):
         assert np.array_equal(out[k], d_one.cpu().numpy()), k
     model, _ = oracle.gpuorder_forward_y(frames[n_frames - 1][:200], weights_blob)
     assert np.array_equal(out[n_frames - 1][:190], model[:190])         # 13x13 locality: the top rows of a crop are the frame's
+
+
+def test_config3_7680x4320_as_8_stripes_of_540_rows(weights_blob):
+    """configs[3] at size and in ITS partition: the 7680x4320 plane (3840x2160 x2.0) as 8 row stripes of 540 rows --
+    (a) every stripe through srcnn_forward_y_rows_dev from exactly the rows a rank would hold (its own 540 + 6 halo rows
+    per interior side), (b) the whole step through srcnn_forward_y_striped_dev with 8 contexts on cuda:0 (halo copies
+    device to device, interior rows first, two edge bands per context).  Both must reproduce the sha256 the CPU model of
+    the kernels' arithmetic gave in the build container, plane and stripe by stripe; two stripe EDGES (rows either side
+    of a cut, where a halo error would show) are compared with the reference arithmetic."""
+    import torch
+    pin = pins("c3_7680x4320")
+    w, h, n = pin["width"], pin["height"], pin["stripes"]
+    assert (w, h, n) == (7680, 4320, 8)
+    from srcnn_cpp_amd.synth import synth_luma
+    y = synth_luma(w, h, frame=0)
+    bounds = [S.stripe_rows(h, n, k) for k in range(n)]
+    assert all(b - a == 540 for a, b in bounds)
+    ctxs = [S.Context(0) for _ in range(n)]
+    try:
+        for c in ctxs:
+            c.set_weights_blob(weights_blob)
+        # (a) stripe by stripe, each from its own halo-extended rows only
+        out_a = np.empty_like(y)
+        for k, (r0, r1) in enumerate(bounds):
+            s0, s1 = max(0, r0 - 6), min(h, r1 + 6)
+            d_in = torch.from_numpy(np.ascontiguousarray(y[s0:s1])).cuda()
+            d_out = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctxs[k].forward_y_rows_dev(d_in.data_ptr(), w, s0, d_out.data_ptr(), w, r0, w, h, r0, r1)
+            ctxs[k].synchronize()
+            out_a[r0:r1] = d_out.cpu().numpy()
+        assert shas([out_a[a:b] for a, b in bounds]) == pin["stripe_gpuorder_sha256"]
+        assert shas([out_a]) == pin["gpuorder_sha256"]
+        # (b) the striped step: 8 contexts, each holding ONLY its 540 rows
+        d_ins = [torch.from_numpy(np.ascontiguousarray(y[a:b])).cuda() for a, b in bounds]
+        d_outs = [torch.zeros((b - a, w), dtype=torch.uint8, device="cuda") for a, b in bounds]
+        torch.cuda.synchronize()
+        for _ in range(2):                                   # twice: the second step waits for the first one's band launches
+            S.forward_y_striped_dev(ctxs, [t.data_ptr() for t in d_ins], w, [t.data_ptr() for t in d_outs], w, w, h)
+        for c in ctxs:
+            c.synchronize()
+        out_b = np.concatenate([t.cpu().numpy() for t in d_outs], axis=0)
+        assert shas([out_b[a:b] for a, b in bounds]) == pin["stripe_gpuorder_sha256"]
+        assert shas([out_b]) == pin["gpuorder_sha256"]
+        # reference arithmetic around two cuts: rows [cut - 40, cut + 40) -- the oracle on a crop is exact >= 6 rows from its ends
+        for cut in (bounds[1][0], bounds[5][0]):
+            a, b = cut - 46, cut + 46
+            r_out, r_pre = oracle.forward_y(y[a:b], weights_blob)
+            got = out_b[a + 6:b - 6]
+            d = np.abs(got.astype(np.int16) - r_out[6:-6].astype(np.int16))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-3
+            frac = np.abs(r_pre[6:-6][d != 0] - np.rint(r_pre[6:-6][d != 0]))
+            assert (frac <= TOL_PRE_ABS).all()
+    finally:
+        for c in ctxs:
+            c.close()

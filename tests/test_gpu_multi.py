@@ -141,3 +141,57 @@ def test_cpp_host_with_several_contexts(tmp_path):
     got = np.fromfile(out_file, np.uint8).reshape(h, w)
     m_out, _ = oracle.gpuorder_forward_y(synth_luma(w, h, frame=n - 1), S.load_weights())
     assert np.array_equal(got, m_out)
+
+
+def test_bench_dead_rank_is_noticed():
+    """Rank 1 dies before the rendezvous; rank 0 would wait in init_process_group for the store timeout (30 min).
+    The launcher's watchdog must stop it and return non-zero within seconds."""
+    import time
+    t = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--gpus", "2",
+                        "--shared-gpu", "--backend", "gloo", "--fault-rank", "1", "--width", "640", "--height", "360"],
+                       capture_output=True, text=True, timeout=300)
+    dt = time.time() - t
+    assert r.returncode == 7 and dt < 30, (r.returncode, dt, r.stderr[-500:])
+    assert "rank 1 exited with code 7" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.parametrize("workload", ["stripe", "frames"])
+def test_bench_cxx_host_equals_python_ranks(workload):
+    """`--host cxx`: ONE process, two contexts, the C ABI's several-GPUs entry points (hipMemcpyPeerAsync halo copies,
+    persistent host threads) -- the second transport of the scaling curve.  Same planes as the one-rank run."""
+    w, h = 1920, 1080
+    extra = ["--workload", "stripe"] if workload == "stripe" else []
+    one = run_bench("--gpus", 1, "--width", w, "--height", h, *(extra or ["--frames", 2]))
+    two = run_bench("--gpus", 2, "--shared-gpu", "--host", "cxx", "--width", w, "--height", h, *extra)
+    assert two["n_gpus"] == 2 and two["config"]["host"] == "cxx" and two["host_us_per_step"] > 0
+    assert two["config"]["output_crc32"] == one["config"]["output_crc32"]
+    assert two["scaling"] == ("strong" if workload == "stripe" else "weak")
+    assert len(two["per_rank_ms_per_step"]) == 2 and two["value"] > 0
+
+
+def test_bench_rccl_unavailable_fails_loudly_or_is_marked_degraded():
+    """--backend nccl on a box where RCCL cannot build the group (two ranks on ONE GPU: RCCL refuses duplicate devices):
+    the default is to give up with a non-zero exit code -- a number measured with the halo rows staged through host memory
+    is not the configs[3] number -- and `--halo-fallback host` runs on, marking the line `"degraded": true`."""
+    common = [sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline", "--steps", "3", "--warmup", "1", "--gpus", "2",
+              "--shared-gpu", "--backend", "nccl", "--workload", "stripe", "--width", "1920", "--height", "1080"]
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-300:])
+    assert "RCCL group unavailable" in r.stderr
+    r = subprocess.run(common + ["--halo-fallback", "host"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])      # the JSON line is the LAST line, also with RCCL's chatter on stdout
+    assert line["degraded"] is True and line["distributed"]["halo_transport"].startswith("host-staged")
+    one = run_bench("--gpus", 1, "--workload", "stripe", "--width", 1920, "--height", 1080)
+    assert line["config"]["output_crc32"] == one["config"]["output_crc32"]
+
+
+def test_bench_line_reports_both_clock_regimes_and_e2e():
+    """The default line carries the contract-as-written figure (`cold_start`: W warm-up + K steps before the pre-warm), the
+    steady-state one, the PCIe-inclusive secondary metric of SURVEY 8d (`e2e`), and what the timed window is."""
+    d = run_bench("--gpus", 1, "--width", 1920, "--height", 1080, "--steps", 10)
+    assert d["cold_start"]["ms_per_step"] > 0 and d["cold_start"]["kernel_ms"] > 0
+    assert d["e2e"]["value"] > 0 and d["e2e"]["output_equals_resident"] is True and d["e2e"]["value"] < d["value"]
+    assert "closing_barrier_ms" in d["timing"]
+    assert d["roofline"]["traffic"] is None or d["pmc_reference"]["traffic"] == d["roofline"]["traffic"]

@@ -71,9 +71,21 @@ def _worker(rank, world, port, q):
             sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), overlap=overlap, via_host=via_host)
             outs.append(sharding.gather_stripes(o, H, world, rank))
         assert sharding.band_plan(H, world, rank) is not None
+        # a persistent StripeStep (buffers and op lists built once) stepped on three different planes, refilled in place
+        reuse_ok = True
+        for via_host in (False, True):
+            buf, o = mine.clone(), torch.zeros_like(mine)
+            stepper = sharding.StripeStep(buf, o, H, world, rank, _oracle_launch_rows(blob), via_host=via_host)
+            for frame in (3, 8, 3):
+                p2 = synth_luma(W, H, frame=frame)
+                buf.copy_(torch.from_numpy(p2[r0:r1].copy()))
+                stepper.step()
+                got = sharding.gather_stripes(o, H, world, rank)
+                if rank == 0:
+                    reuse_ok = reuse_ok and np.array_equal(got.numpy(), oracle.forward_y(p2, blob)[0])
         if rank == 0:
             ref, _ = oracle.forward_y(plane, blob)
-            q.put(("ok", bool(np.array_equal(full.numpy(), ref)) and all(np.array_equal(o.numpy(), ref) for o in outs)))
+            q.put(("ok", bool(np.array_equal(full.numpy(), ref)) and all(np.array_equal(o.numpy(), ref) for o in outs) and reuse_ok))
         # frame sharding: the ranges tile the stream, nothing is exchanged
         a, b = sharding.frame_range(11, world, rank)
         t = torch.zeros(11, dtype=torch.int64)

@@ -1,7 +1,8 @@
 // host_demo.cpp -- a plain C++ host (no OpenCV, no HIP headers) driving the HIP
 // path through the reference's own call surface (include/srcnn_amd.hpp):
 //   Convolution99x11 + Convolution55  exactly as src/srcnn.cpp:602-627 calls them,
-//   then the fused ForwardY, and checks that both give the same plane.
+//   then the fused ForwardY, then the same two calls on srcnn::DevicePlane<float> (the 32-plane map never leaves the
+//   GPU), and checks that all three give the same plane.
 // Build: g++ -std=c++17 -Iinclude tools/host_demo.cpp -Lsrcnn_cpp_amd -lsrcnn_amd \
 //            -Wl,-rpath,$PWD/srcnn_cpp_amd -o build/host_demo
 // Run:   build/host_demo srcnn_cpp_amd/data/srcnn915_weights.f32 W H out.u8
@@ -38,7 +39,7 @@ int main(int argc, char **argv)
     const float b3 = blob[7328];
     auto w3 = reinterpret_cast<const float(*)[5][5]>(blob + 7329);
 
-    srcnn::Plane<unsigned char> y(W, H), out_a(W, H), out_b(W, H);
+    srcnn::Plane<unsigned char> y(W, H), out_a(W, H), out_b(W, H), out_c(W, H);
     for (int r = 0; r < H; ++r)
         for (int c = 0; c < W; ++c) y.at(r, c) = synth(c, r, 0, W, H);
     try {
@@ -49,11 +50,19 @@ int main(int argc, char **argv)
         srcnn::Convolution55(conv2, out_a, w3, b3);
         // the fused replacement
         srcnn::ForwardY(y, out_b, w1, b1, w2, b2, w3, b3);
+        // the same two calls with the 32 planes kept on the GPU: only the vector's element type differs (:602-607)
+        std::vector<srcnn::DevicePlane<float>> conv2d = srcnn::DevicePlanes<float>(32, W, H);
+        srcnn::Convolution99x11(y, conv2d, w1, b1, w2, b2);
+        srcnn::Convolution55(conv2d, out_c, w3, b3);
+        // ... and the device map is the map the host-plane call returned
+        const srcnn::Plane<float> back = conv2d[17].download();
+        if (std::memcmp(back.data, conv2[17].data, sizeof(float) * (size_t)W * H) != 0) { std::fprintf(stderr, "device map != host map\n"); return 6; }
     } catch (const srcnn::Error &e) {
         std::fprintf(stderr, "srcnn error %d: %s\n", e.code, e.what());
         return 3;
     }
     if (std::memcmp(out_a.data, out_b.data, (size_t)W * H) != 0) { std::fprintf(stderr, "fused != unfused\n"); return 4; }
+    if (std::memcmp(out_a.data, out_c.data, (size_t)W * H) != 0) { std::fprintf(stderr, "device planes != host planes\n"); return 7; }
     unsigned long sum = 0;
     for (size_t i = 0; i < (size_t)W * H; ++i) sum += out_a.storage[i];
     FILE *o = std::fopen(argv[4], "wb");

@@ -14,6 +14,7 @@ run --steps 20 --width 576 --height 576                         # configs[0] pla
 run --steps 5 --path host --frames 32                           # stream of host frames, transfers overlapped
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
 run --steps 3 --warmup 1 --path surface                         # the reference call surface on host buffers (32 f32 planes over PCIe)
+run --steps 10 --path surface-dev                              # the same two call sites with the 32 planes kept on the device (DevicePlane<float>)
 run --steps 20 --width 1920 --height 1080                       # a 1080p plane
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode

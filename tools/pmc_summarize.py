@@ -85,6 +85,9 @@ try:
 except Exception:
     head = ""
 traffic_rec["_taken_at"] = {"date": datetime.date.today().isoformat(), "commit": head or "unknown (the GPU box holds no .git)"}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from srcnn_cpp_amd.build import kernel_sources_fingerprint
+traffic_rec["_kernel_sources"] = kernel_sources_fingerprint()      # bench.py quotes these figures only for this build
 
 # the two reference functions alone (unfused path, one 3840x2160 frame): bytes per launch against the algorithmic 1 + 128 B/pixel
 unf = defaultdict(lambda: defaultdict(list))
