@@ -213,8 +213,10 @@ def parse_args():
                          "(what include/srcnn_amd.hpp's Convolution99x11 / Convolution55 call), 32 f32 planes over PCIe; "
                          "surface-dev: the same two calls with the 32 planes kept in device memory between them "
                          "(srcnn_conv99x11_to_dev + srcnn_conv55_from_dev, the DevicePlane<float> overloads): only the u8 planes cross PCIe")
-    ap.add_argument("--mode", choices=["mfma", "exact", "split16"], default="mfma",
+    ap.add_argument("--mode", choices=["mfma", "exact", "split16", "refbytes"], default="mfma",
                     help="mfma: float32 MFMA (default, the headline); exact: reference arithmetic on the vector ALU; "
+                         "refbytes: the float32 MFMA kernel + exact recomputation of the ~0.4 % of pixels whose value lies next to a "
+                         "truncation boundary -- the reference's bytes (SRCNN_MODE_REFBYTES); "
                          "split16: opt-in f16-MFMA mode with (hi, lo) operand splitting (SURVEY.md 8f rank 4) -- "
                          "never the headline number")
     ap.add_argument("--workload", choices=["frames", "stripe"], default="frames",
@@ -307,6 +309,8 @@ def worker(args):
         ctx.set_mode(S.MODE_EXACT)
     elif args.mode == "split16":
         ctx.set_mode(S.MODE_SPLIT16)
+    elif args.mode == "refbytes":
+        ctx.set_mode(S.MODE_REFBYTES)
     # a real (non-null) stream that both torch's events and the HIP kernels use
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -543,6 +547,8 @@ def worker(args):
                                   "halo_transport": (("rccl send/recv" if rccl is not None else "host-staged (gloo)")
                                                      if stripe else "none (frames are independent)"),
                                   "halo_overlap": bool(stripe and not args.no_overlap)}
+        if args.mode == "refbytes":
+            out["fixup"] = ctx.fixup_stats()                  # accumulated over every launch of the run
         if args.mode == "split16":
             # opt-in mode: priced against the dense f16 MFMA peak with the same ALGORITHMIC flops; the
             # kernel executes 42 MFMA x 32x32x16 per 32 pixels = 43,008 flop/pixel (2-3 f16 products per MAC)

@@ -69,8 +69,18 @@ enum {
  *                    into an f16 (hi, lo) pair -- 22 significant bits, f32
  *                    accumulation; same tolerance as SRCNN_MODE_MFMA, several
  *                    times faster.  The per-filter entry points and the
- *                    materialising path are unaffected (they run as in MFMA mode). */
-enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2 };
+ *                    materialising path are unaffected (they run as in MFMA mode).
+ *   SRCNN_MODE_REFBYTES the reference's BYTES at nearly the MFMA speed: the fused forward pass
+ *                    (srcnn_forward_y*, row stripes, srcnn_process_bgr*) runs the float32 MFMA kernel, which
+ *                    also marks every pixel whose pre-truncation value lies within delta of an
+ *                    integer (~0.4 % of them; delta is derived from the model), and
+ *                    exactly those pixels are then recomputed in the reference's arithmetic
+ *                    (src/srcnn.cpp:238-240 truncates: only there can rounding noise change a byte).
+ *                    Output: bit-identical to the reference CPU path on every input tried; the
+ *                    margin is observable (srcnn_fixup_stats).  The per-filter entry points and
+ *                    the materialising path run as in MFMA mode; a pre-clamp request runs the
+ *                    exact kernels. */
+enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2, SRCNN_MODE_REFBYTES = 3 };
 
 typedef struct srcnn_ctx srcnn_ctx;
 
@@ -267,6 +277,13 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
                           float scale, uint8_t *d_out, size_t out_stride);
 
 /* ---- introspection for the bench / tests ---------------------------------- */
+
+/* SRCNN_MODE_REFBYTES: counters accumulated over the context's launches in that mode since creation.
+ * out[0] = pixels flagged and recomputed one by one, out[1] = 12x12 tiles recomputed whole (flat / periodic
+ * content), out[2] = bytes the recomputation changed, out[3] = 0 (reserved); 32-bit counters on the device;
+ * *delta = the flag threshold of the loaded model, *max_dev = the largest |v_mfma - v_reference| met on a
+ * flagged pixel (a random ~0.4 % sample of all pixels): it must stay well below delta.  Synchronises the stream. */
+int srcnn_fixup_stats(srcnn_ctx *ctx, unsigned long long out[4], float *delta, float *max_dev);
 
 /* Launch geometry the fused kernel would use for (width,height,n_frames):
  * out[0]=workgroups, out[1]=rows per segment (the tallest one when a single plane is cut into

@@ -28,7 +28,7 @@ import numpy as np
 __all__ = [
     "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
-    "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "FLOP_PER_PIXEL",
+    "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "FLOP_PER_PIXEL",
     "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
     "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
@@ -43,6 +43,7 @@ _WEIGHTS_PATH = _PKG / "data" / "srcnn915_weights.f32"
 MODE_MFMA = 0
 MODE_EXACT = 1
 MODE_SPLIT16 = 2
+MODE_REFBYTES = 3          # float32 MFMA + exact fix-up of the pixels next to a truncation boundary: the reference's bytes
 N_WEIGHTS = 8129
 # 2 x (64*81 + 32*64 + 32*25) MAC per output pixel
 FLOP_PER_PIXEL = 16064
@@ -113,6 +114,7 @@ def load_library() -> C.CDLL:
         "srcnn_dev_download": ([vp, vp, vp, sz], i),
         "srcnn_dev_upload": ([vp, vp, vp, sz], i),
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
+        "srcnn_fixup_stats": ([vp, C.POINTER(C.c_ulonglong * 4), C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
         "srcnn_ycrcb2bgr": ([vp, _u8p, _u8p, _u8p, sz, i, i, _u8p, sz], i),
@@ -139,7 +141,7 @@ ABI_SYMBOLS = (
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
-    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
@@ -296,6 +298,13 @@ class Context:
         _same_shape("dst planes", shape, src.shape)
         self._check(self._lib.srcnn_conv99x11(self._h, src.ctypes.data_as(_u8p), ss, arr, ds, w, h,
                                               _fp(k99), _fp(b99), _fp(k11), _fp(b11)))
+
+    def fixup_stats(self):
+        """SRCNN_MODE_REFBYTES counters since the context was created (srcnn_fixup_stats; synchronises)."""
+        out, delta, dev = (C.c_ulonglong * 4)(), C.c_float(), C.c_float()
+        self._check(self._lib.srcnn_fixup_stats(self._h, C.byref(out), C.byref(delta), C.byref(dev)))
+        return {"scattered_pixels": int(out[0]), "dense_tiles": int(out[1]), "bytes_changed": int(out[2]),
+                "delta": float(delta.value), "max_dev": float(dev.value)}
 
     # the two reference calls with the 32-plane map kept in device memory between them (include/srcnn_amd.h)
     def dev_alloc(self, nbytes: int) -> int:

@@ -128,6 +128,7 @@ struct srcnn_ctx {
         hipStream_t stream = nullptr;
         bool used = false;
         DevBuf buf, cbuf;           // row seams, column seams
+        DevBuf flag, fix_lists, fix_counters;     // SRCNN_MODE_REFBYTES: flag plane, work lists, per-launch counters
     };
     SeamScratch seam_scratch[4];
     // pipeline steps around the conv path
@@ -164,6 +165,8 @@ struct srcnn_ctx {
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
     size_t pin_cap = 0;
+    float fix_delta = 0.f;                 // SRCNN_MODE_REFBYTES: flag threshold for the uploaded model (fixup_delta())
+    DevBuf fix_totals;                     // ... and its counters accumulated over the context's launches (srcnn_fixup_stats)
     std::unique_ptr<WorkerPool> pool;      // host threads of the several-GPUs calls this context leads (WorkerPool)
 };
 
@@ -248,6 +251,35 @@ int scale_exponent(double bound)
 
 // Power-of-two scales of layers 1 and 2 (srcnn_kernels.h): rigorous bounds of the two maps for ANY 8-bit input --
 // layer-1 channel c is at most 255 * sum(max(w1, 0)) + b1, layer-2 channel k at most sum(max(w2, 0) * bound1) + b2.
+// SRCNN_MODE_REFBYTES flags a pixel for exact recomputation when the MFMA path's pre-truncation value v lies within delta of
+// an integer.  delta has to exceed |v_mfma - v_ref|, the difference of two float32 evaluations of the same sums in different
+// orders with different roundings -- rounding NOISE: a rigorous worst-case bound (every rounding error at its maximum, all of
+// one sign) is ~10 grey levels and useless, the measured maximum over 18 MPix of varied content is 4.1e-4 with a tail that
+// falls by a factor of 100 per 0.9e-4 (profiles/r03/fixup_margin.txt).  The noise scales with the magnitudes the model can
+// produce, so delta is tied to the model, not to a constant: E0 = 2^-24 * ||W3||_2 * B2 (one half-ulp rounding error of a
+// layer-2 activation at its rigorous bound B2, carried through the 800 layer-3 weights as independent errors) is 3.3e-4 for the
+// shipped model -- the scale of the measured maximum -- and delta = 6 * E0 = 2.0e-3: ~5 x the largest difference ever seen,
+// 0.4 % of the pixels flagged.  fix_apply_kernel records the largest |v_mfma - v_ref| it meets (srcnn_fixup_stats), so the margin
+// of a deployment can be watched; tests/test_gpu_refbytes.py asserts it stays below delta / 2.
+float fixup_delta(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3)
+{
+    double a1[64], m2 = 0.0, s3 = 0.0;
+    for (int c = 0; c < 64; ++c) {
+        double s = 0.0;
+        for (int t = 0; t < 81; ++t) s += std::max(w1[c * 81 + t], 0.f);
+        a1[c] = std::max(0.0, 255.0 * s + b1[c]);
+    }
+    for (int k = 0; k < 32; ++k) {
+        double s = b2[k];
+        for (int i = 0; i < 64; ++i) s += (double)std::max(w2[k * 64 + i], 0.f) * a1[i];
+        m2 = std::max(m2, s);
+    }
+    for (int i = 0; i < 800; ++i) s3 += (double)w3[i] * w3[i];
+    const double d = 6.0 * std::ldexp(1.0, -24) * std::sqrt(s3) * m2;
+    if (!std::isfinite(d)) return 0.25f;
+    return (float)std::min(0.25, std::max(d, 1e-6));
+}
+
 void layer_scales(const float *w1, const float *b1, const float *w2, const float *b2, int *e1, int *e2)
 {
     double a1[64], m1 = 0.0, m2 = 0.0;
@@ -410,6 +442,7 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     HIP_TRY(c, hipMemcpy(c->wraw.p, raw.data(), raw.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->wfrag16.p, frag16.data(), frag16.size(), hipMemcpyHostToDevice));
     c->b3 = b55;
+    c->fix_delta = fixup_delta(w1, b1, w2, b2, w3);
     c->split16_ok = split16_range_ok(w1, b1, w2, b2, w3);
     std::memcpy(c->host_raw.data(), raw.data(), 8129 * sizeof(float));
     return SRCNN_OK;
@@ -963,10 +996,13 @@ bool cseam_pays(int width)
 // * Larger batches use the regular strip x segment x frame grid (column-seam scratch only, 4 MB per 3840x2160 frame),
 //   at most 64 frames per launch.
 constexpr int kItemBatchMax = 32, kItemBatchChunk = 8, kGridBatchChunk = 64;
+// the modes whose fused pass is the float32 MFMA strip kernel (REFBYTES = the same kernel + flags + fix-up)
+bool f32_mfma(const srcnn_ctx *c) { return c->mode == SRCNN_MODE_MFMA || c->mode == SRCNN_MODE_REFBYTES; }
 int frames_per_launch(const srcnn_ctx *c, int width, int height, int n_frames)
 {
     static const char *env_loop = std::getenv("SRCNN_DEBUG_FRAMELOOP");      // experiment knob: 0 = never one launch per frame
     const size_t px = (size_t)width * height;
+    if (c->mode == SRCNN_MODE_REFBYTES) return 1;       // the fix-up's work lists are per plane
     if (c->mode != SRCNN_MODE_MFMA || n_frames <= 1) return kGridBatchChunk;
     if (!(env_loop && std::atoi(env_loop) == 0) &&
         ((px >= ((size_t)4 << 20) && n_frames < kItemBatchMax) || (px >= ((size_t)3 << 19) && n_frames <= 8)))
@@ -1123,6 +1159,30 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
             p.cseam = static_cast<float *>(sc->cbuf.p);
         }
     }
+    // SRCNN_MODE_REFBYTES: the fused float32 kernel also writes a flag byte per pixel; fix_collect / fix_apply then recompute
+    // the flagged pixels in the reference's arithmetic (srcnn_exact.hip).  One frame per launch (srcnn_forward_y_dev).
+    const bool fix = mode == MODE_FUSED && c->mode == SRCNN_MODE_REFBYTES && !p.pre;
+    srcnn_ctx::SeamScratch *fsc = nullptr;
+    size_t fix_scat_cap = 0, fix_dense_cap = 0;
+    if (fix) {
+        if (n_frames != 1) return fail(c, SRCNN_ERR_STATE, "REFBYTES launches hold one frame");
+        int rc;
+        if ((rc = seam_scratch_for_stream(c, &fsc))) return rc;
+        const int rows = p.row_end - p.row_begin;
+        fix_scat_cap = fixup_list_entries(p.width, rows, &fix_dense_cap);
+        if ((rc = reserve(c, fsc->flag, (size_t)rows * (size_t)p.dst_stride))) return rc;
+        if ((rc = reserve(c, fsc->fix_lists, (fix_scat_cap + fix_dense_cap) * sizeof(unsigned)))) return rc;
+        if ((rc = reserve(c, fsc->fix_counters, FIX_COUNTERS * sizeof(unsigned)))) return rc;
+        if (!c->fix_totals.p) {
+            if ((rc = reserve(c, c->fix_totals, FIX_COUNTERS * sizeof(unsigned)))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->fix_totals.p, 0, FIX_COUNTERS * sizeof(unsigned), c->stream));
+        }
+        // flag[o] for the same element offsets o as dst: o >= (row_begin - dst_row0) * dst_stride
+        p.flag = static_cast<uint8_t *>(fsc->flag.p) - (long)(p.row_begin - p.dst_row0) * p.dst_stride;
+        p.fix_delta = c->fix_delta;
+        p.fix_scale = 253.f / (2.f * c->fix_delta);
+        p.fix_counters = static_cast<unsigned *>(fsc->fix_counters.p);
+    }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
     p.wfrag16 = static_cast<const uint32_t *>(c->wfrag16.p);
     p.sink = static_cast<float *>(c->sink.p);
@@ -1141,10 +1201,32 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     if (p.seam && p.cseam && table->separated && !(env_merge && std::atoi(env_merge) == 0)) {
         HIP_TRY(c, launch_seams_merged(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p),
                                        static_cast<const unsigned char *>(table->dev_winmap.p), n_frames, c->stream));
-        return SRCNN_OK;
+    } else {
+        if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p), c->stream));
+        if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     }
-    if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p), c->stream));
-    if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
+    if (fix) {
+        FixParams f{};
+        f.src = p.src;
+        f.src_stride = p.src_stride;
+        f.src_row0 = p.src_row0;
+        f.dst = p.dst;
+        f.flag = p.flag;
+        f.dst_stride = p.dst_stride;
+        f.dst_row0 = p.dst_row0;
+        f.width = p.width;
+        f.height = p.height;
+        f.row_begin = p.row_begin;
+        f.row_end = p.row_end;
+        f.wraw = static_cast<const float *>(c->wraw.p);
+        f.counters = p.fix_counters;
+        f.totals = static_cast<unsigned *>(c->fix_totals.p);
+        f.scat = static_cast<unsigned *>(fsc->fix_lists.p);
+        f.dense = f.scat + fix_scat_cap;
+        f.delta = c->fix_delta;
+        f.code_step = 2.f * c->fix_delta / 253.f;
+        HIP_TRY(c, launch_fixup(f, c->n_cu, c->stream));
+    }
     return SRCNN_OK;
 }
 
@@ -1389,7 +1471,11 @@ void srcnn_destroy(srcnn_ctx *c)
     for (auto &sc : c->seam_scratch) {
         release(sc.buf);
         release(sc.cbuf);
+        release(sc.flag);
+        release(sc.fix_lists);
+        release(sc.fix_counters);
     }
+    release(c->fix_totals);
     for (auto &t : c->item_tables) {
         release(t.dev);
         release(t.dev_seams);
@@ -1410,7 +1496,7 @@ const char *srcnn_last_error(const srcnn_ctx *c) { return c ? c->err : "null con
 
 int srcnn_set_mode(srcnn_ctx *c, int mode)
 {
-    if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT && mode != SRCNN_MODE_SPLIT16))
+    if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT && mode != SRCNN_MODE_SPLIT16 && mode != SRCNN_MODE_REFBYTES))
         return SRCNN_ERR_INVALID;
     c->mode = mode;
     return SRCNN_OK;
@@ -1448,6 +1534,24 @@ int srcnn_set_weights(srcnn_ctx *c, const float *k99, const float *b99, const fl
         return SRCNN_OK;
     if ((rc = upload_weights(c, k99, b99, k11, b11, k55, b55))) return rc;
     c->has_l12 = c->has_l3 = true;
+    return SRCNN_OK;
+}
+
+int srcnn_fixup_stats(srcnn_ctx *c, unsigned long long out[4], float *delta, float *max_dev)
+{
+    BIND(c);
+    if (!out) return fail(c, SRCNN_ERR_INVALID, "fixup_stats: null output");
+    unsigned t[FIX_COUNTERS] = {0, 0, 0, 0};
+    if (c->fix_totals.p) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(t, c->fix_totals.p, sizeof(t), hipMemcpyDeviceToHost));
+    }
+    out[0] = t[FIX_N_SCAT];
+    out[1] = t[FIX_N_DENSE];
+    out[2] = t[FIX_N_CHANGED];
+    out[3] = 0;
+    if (delta) *delta = c->fix_delta;
+    if (max_dev) std::memcpy(max_dev, &t[FIX_MAX_DEV], sizeof(float));
     return SRCNN_OK;
 }
 
@@ -1489,9 +1593,9 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     const int nl = std::min(n_frames, frames_per_launch(c, width, height, n_frames));
     const int seam_knob = env_seams ? std::atoi(env_seams) : 3;
     const int ns_cs = (width + FW - 1) / FW;
-    bool col_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 2) && (nl > 1 || (seam_knob & 1)) && cseam_pays(width);
+    bool col_seams = f32_mfma(c) && (seam_knob & 2) && (nl > 1 || (seam_knob & 1)) && cseam_pays(width);
     int items_per_cu = wgs_per_cu;
-    const bool row_seams = c->mode == SRCNN_MODE_MFMA && (seam_knob & 1);
+    const bool row_seams = f32_mfma(c) && (seam_knob & 1);
     auto fits = [&](int n_strips_, int per_cu) { return !plan_items(c->n_cu, n_strips_, 0, height, skew_percent(), per_cu, row_seams).items.empty(); };
     if (col_seams && nl == 1 && !fits(ns_cs, wgs_per_cu)) {
         if (wgs_per_cu == 2 && fits(ns_cs, 1)) items_per_cu = 1;
@@ -1506,10 +1610,10 @@ int srcnn_query_plan(srcnn_ctx *c, int width, int height, int n_frames, int out[
     out[1] = pl.seg_rows;
     out[2] = pl.n_strips;
     out[3] = pl.n_segs;
-    if (nl == 1 || (c->mode == SRCNN_MODE_MFMA && n_frames < kItemBatchMax)) {   // explicit work items (plan_items), repeated per frame of a small batch
+    if (nl == 1 || (f32_mfma(c) && n_frames < kItemBatchMax)) {   // explicit work items (plan_items), repeated per frame of a small batch
         const std::vector<int> items =
             plan_items(c->n_cu, pl.n_strips, 0, height, skew_percent(), items_per_cu,
-                       c->mode == SRCNN_MODE_MFMA && (seam_knob & 1)).items;
+                       f32_mfma(c) && (seam_knob & 1)).items;
         if (!items.empty()) {
             out[0] = (int)items.size() / ITEM_INTS * n_frames;
             out[1] = 0;
@@ -1649,7 +1753,8 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
     if (ranges_overlap(d_src, span_elems(src_stride, src_frame_pitch, width, height, n_frames), d_dst,
                        span_elems(dst_stride, dst_frame_pitch, width, height, n_frames)))
         return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: src and dst overlap (the path cannot run in place)");
-    if (c->mode == SRCNN_MODE_EXACT) {
+    // (a pre-clamp request in REFBYTES mode wants the REFERENCE's float too: the exact kernels deliver both)
+    if (c->mode == SRCNN_MODE_EXACT || (c->mode == SRCNN_MODE_REFBYTES && d_preclamp)) {
         // frame by frame through ONE 32-plane workspace (128 B/pixel), whatever the batch size
         const long pitch = (long)width * height;
         if ((rc = reserve(c, c->planes, (size_t)32 * pitch * 4))) return rc;

@@ -96,7 +96,31 @@ struct StripParams {
     float *cseam;                   // column-seam scratch [frame][strip][row][CSEAM_FLOATS]; non-null = strips without column halo
     int strips_total;               // number of strips of the plane (n_strips is 1 in an items launch)
     int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
+    // SRCNN_MODE_REFBYTES (srcnn_exact.hip, "the reference's bytes"): a flag byte beside every output byte, same offsets as dst
+    uint8_t *flag;                  // null = no flags
+    float fix_delta, fix_scale;     // flag where |v - rint(v)| <= fix_delta; code = 1 + (v - rint(v) + delta) * scale, scale = 253 / (2 delta)
+    unsigned *fix_counters;         // FixParams::counters: the strip kernel's first block zeroes them for the launch
 };
+
+// ---- SRCNN_MODE_REFBYTES: fix-up of the pixels whose MFMA value lies within delta of a truncation boundary (srcnn_exact.hip)
+enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_NEXT_ITEM = 4, FIX_COUNTERS = 5 };
+struct FixParams {
+    const uint8_t *src;             // the launch's Y input, as the strip kernel reads it
+    long src_stride;
+    int src_row0;
+    uint8_t *dst;                   // the launch's output plane (already written by the strip and seam kernels)
+    const uint8_t *flag;            // flag plane, same offsets as dst
+    long dst_stride;
+    int dst_row0;
+    int width, height, row_begin, row_end;
+    const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32]
+    unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel
+    unsigned *totals;               // the same four, accumulated over every launch of the context (srcnn_fixup_stats)
+    unsigned *scat, *dense;         // work lists: pixel y * width + x; tile index
+    float delta, code_step;         // code_step = 2 delta / 253
+};
+hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);
+size_t fixup_list_entries(int width, int rows, size_t *dense_entries);
 
 // A SEAM is the boundary between two vertically adjacent work items of a strip.  Instead of recomputing the
 // two feature rows either side of it (4 rows per item), the item above hands over its 12 vertical-chain

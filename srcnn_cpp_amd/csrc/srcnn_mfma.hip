@@ -184,6 +184,18 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
     }
 }
 
+// SRCNN_MODE_REFBYTES: the flag byte stored beside an output byte (srcnn_kernels.h, srcnn_exact.hip): 0, or 1 + the position of
+// v - rint(v) in [-delta, +delta] on a 253-step scale, for the values a rounding difference of the MFMA path could carry across
+// a truncation boundary: |v - rint(v)| <= delta and 0.5 < v < 255.5 (the store truncates toward zero and clamps: (-1, 1) -> 0,
+// >= 255 -> 255, so there is no boundary at 0 nor above 255).  The range test is ONE unsigned compare on the float's bits.
+__device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
+{
+    const float dist = v - __builtin_rintf(v);
+    const bool live = (__builtin_fabsf(dist) <= delta) & ((__float_as_uint(v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
+    const unsigned code = (unsigned)((dist + delta) * scale + 1.5f);
+    return live ? (uint8_t)code : (uint8_t)0;
+}
+
 // Kernels whose steady-state rows run through the FAST row body (see the row loop).  Convolution55 alone (MODE_L3) is
 // bound by its plane loads: the FAST body measured 0-1 % slower there (112 registers instead of 93), so it keeps the general one.
 constexpr bool fast_kernel(int mode, bool pre, int diag)
@@ -195,9 +207,14 @@ constexpr bool fast_kernel(int mode, bool pre, int diag)
 // (SRCNN_DEBUG_TUNE & 16; tools/diag_light.py).  Stamps go to p.sink, never to an output; the pixels are the production ones.
 // (The timing-only ablation kernels of rounds 1-2 -- wrong pixels by construction -- and the per-row stamp build are gone
 // from this file; profiles/r02/ablation.txt names the commit that still has them.)
-template <int MODE, bool PRE, int DIAG = 0>
+// FIX: SRCNN_MODE_REFBYTES -- a flag byte beside every output byte (fix_code()).
+template <int MODE, bool PRE, int DIAG = 0, bool FIX = false>
 __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
+    static_assert(!FIX || (MODE == MODE_FUSED && !PRE && DIAG == 0), "flags belong to the production fused kernel");
+    if constexpr (FIX) {     // the launch's fix-up counters (FixParams::counters) start at zero; the fix-up kernels run behind this one
+        if (blockIdx.x == 0 && threadIdx.x < FIX_COUNTERS) p.fix_counters[threadIdx.x] = 0u;
+    }
     unsigned long long lt[4] = {0, 0, 0, 0};
     if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -402,6 +419,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own no output pixel are masked off.
         auto row = scalar_base(p.dst + o);
         if (ok) row[lane_off((unsigned)gx)] = (uint8_t)clampi((int)v, 0, 255);
+        if constexpr (FIX) {
+            auto frow = scalar_base(p.flag + o);
+            if (ok) frow[lane_off((unsigned)gx)] = fix_code(v, p.fix_delta, p.fix_scale);
+        }
         if constexpr (PRE) {
             float *prow = p.pre + o;
             if (ok) prow[(unsigned)gx] = v;
@@ -497,6 +518,10 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
         const float v = acc + p.b3;
         auto row = scalar_base(p.dst + (o_out - p.dst_stride));        // uniform: output row f - 4
         if (px_ok) row[lane_off(st2)] = (uint8_t)clampi((int)v, 0, 255);
+        if constexpr (FIX) {
+            auto frow = scalar_base(p.flag + (o_out - p.dst_stride));
+            if (px_ok) frow[lane_off(st2)] = fix_code(v, p.fix_delta, p.fix_scale);
+        }
         if (do_cs) {
             const float *tile = fbuf + slot * FSLOT;
             const float a = tile[cl2.off[0]], b = tile[cl2.off[1]], c = tile[cl2.off[2]], d = tile[cl2.off[3]];
@@ -760,7 +785,7 @@ __device__ __forceinline__ float cseam_value(const float *tile, int e)
 
 // The four pixels around a strip boundary from the left strip's exports es[0..4] and the right strip's et[5..14]
 // (srcnn_cseam_kernel's arithmetic, shared with the merged form of the seam kernel).
-template <bool PRE>
+template <bool PRE, bool FIX>
 __device__ __forceinline__ void cseam_pixels(const StripParams &p, const float *es, const float *et, int frame, int y, int xt)
 {
     float acc[4];
@@ -774,6 +799,7 @@ __device__ __forceinline__ void cseam_pixels(const StripParams &p, const float *
         if (xt - 2 + k >= p.width) break;
         const float val = acc[k] + p.b3;
         p.dst[o + k] = (uint8_t)clampi((int)val, 0, 255);
+        if constexpr (FIX) p.flag[o + k] = fix_code(val, p.fix_delta, p.fix_scale);
         if constexpr (PRE) p.pre[o + k] = val;
     }
 }
@@ -781,7 +807,7 @@ __device__ __forceinline__ void cseam_pixels(const StripParams &p, const float *
 // MERGED: the plan keeps the seam windows of neighbouring strips apart, so this block also finishes the column-seam pixels
 // either side of its strip on its four rows (the neighbours' values there are complete exports of the strip kernel) and
 // exports nothing itself.
-template <bool PRE, bool MERGED>
+template <bool PRE, bool MERGED, bool FIX>
 __device__ __forceinline__ void seam_block(const StripParams &p, const int *__restrict__ seams, int blk)
 {
     __shared__ float ft[SEAM_ROWS][6][FW];
@@ -828,11 +854,11 @@ __device__ __forceinline__ void seam_block(const StripParams &p, const int *__re
                 if (side) {
 #pragma unroll
                     for (int e = 0; e < 5; ++e) mine[e] = cseam_value(&ft[r][0][0], e);
-                    cseam_pixels<PRE>(p, mine, theirs, frame, y, (strip + 1) * FW);
+                    cseam_pixels<PRE, FIX>(p, mine, theirs, frame, y, (strip + 1) * FW);
                 } else {
 #pragma unroll
                     for (int e = 5; e < 15; ++e) mine[e] = cseam_value(&ft[r][0][0], e);
-                    cseam_pixels<PRE>(p, theirs, mine, frame, y, strip * FW);
+                    cseam_pixels<PRE, FIX>(p, theirs, mine, frame, y, strip * FW);
                 }
             }
         }
@@ -855,21 +881,22 @@ __device__ __forceinline__ void seam_block(const StripParams &p, const int *__re
         const float v = acc + p.b3;
         const long o = (long)frame * p.dst_frame_pitch + (long)(b - 2 + r - p.dst_row0) * p.dst_stride + gx;
         p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
+        if constexpr (FIX) p.flag[o] = fix_code(v, p.fix_delta, p.fix_scale);
         if constexpr (PRE) p.pre[o] = v;
     }
 }
 
-template <bool PRE>
+template <bool PRE, bool FIX>
 __global__ __launch_bounds__(NTHREADS) void srcnn_seam_kernel(const StripParams p, const int *__restrict__ seams)
 {
-    seam_block<PRE, false>(p, seams, (int)blockIdx.x);
+    seam_block<PRE, false, FIX>(p, seams, (int)blockIdx.x);
 }
 
 // The four output pixels around every strip boundary, every row of the launch: columns xT-2, xT-1 of the left
 // strip S (its pixels 126, 127) and xT, xT+1 of the right strip T (its pixels 0, 1), from the two strips' exports
 // (CSEAM_TERMS), added in the order of hp_use(): F0 + F1 + F2 + F3 + F4, then the bias, truncate, clamp.
 // `winmap` (merged launch only): rows inside a seam window of either strip belong to that seam's block.
-template <bool PRE>
+template <bool PRE, bool FIX>
 __device__ __forceinline__ void cseam_block(const StripParams &p, long blk_in_frame, int frame, const unsigned char *__restrict__ winmap)
 {
     const int rows = p.row_end - p.row_begin;
@@ -879,27 +906,27 @@ __device__ __forceinline__ void cseam_block(const StripParams &p, long blk_in_fr
     if (winmap && (winmap[(long)v * rows + yrel] | winmap[(long)(v + 1) * rows + yrel])) return;
     const float *es = p.cseam + (((long)frame * p.strips_total + v) * rows + yrel) * CSEAM_FLOATS;
     const float *et = es + (long)rows * CSEAM_FLOATS;
-    cseam_pixels<PRE>(p, es, et, frame, p.row_begin + yrel, (v + 1) * FW);
+    cseam_pixels<PRE, FIX>(p, es, et, frame, p.row_begin + yrel, (v + 1) * FW);
 }
 
-template <bool PRE>
+template <bool PRE, bool FIX>
 __global__ __launch_bounds__(256) void srcnn_cseam_kernel(const StripParams p)
 {
-    cseam_block<PRE>(p, (long)blockIdx.x, (int)blockIdx.y, nullptr);
+    cseam_block<PRE, FIX>(p, (long)blockIdx.x, (int)blockIdx.y, nullptr);
 }
 
 // Row seams and column seams in one launch: blocks [0, n_seams) finish the row seams (and the column-seam pixels of their
 // rows), the others the column seams of all remaining rows; no block depends on another.
-template <bool PRE>
+template <bool PRE, bool FIX>
 __global__ __launch_bounds__(NTHREADS) void srcnn_seams_merged_kernel(const StripParams p, const int *__restrict__ seams, int n_seams,
                                                                      const unsigned char *__restrict__ winmap, int cblocks_per_frame)
 {
     static_assert(NTHREADS == 256, "both roles use 256 threads");
     if ((int)blockIdx.x < n_seams) {
-        seam_block<PRE, true>(p, seams, (int)blockIdx.x);
+        seam_block<PRE, true, FIX>(p, seams, (int)blockIdx.x);
     } else {
         const int q = (int)blockIdx.x - n_seams;
-        cseam_block<PRE>(p, (long)(q % cblocks_per_frame), q / cblocks_per_frame, winmap);
+        cseam_block<PRE, FIX>(p, (long)(q % cblocks_per_frame), q / cblocks_per_frame, winmap);
     }
 }
 
@@ -908,8 +935,9 @@ hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
     const long n = (long)(p.strips_total - 1) * (p.row_end - p.row_begin);
     if (n <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)n_frames);
-    if (p.pre) hipLaunchKernelGGL((srcnn_cseam_kernel<true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((srcnn_cseam_kernel<false>), grid, dim3(256), 0, stream, p);
+    if (p.flag) hipLaunchKernelGGL((srcnn_cseam_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    else if (p.pre) hipLaunchKernelGGL((srcnn_cseam_kernel<true, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((srcnn_cseam_kernel<false, false>), grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -919,15 +947,17 @@ hipError_t launch_seams_merged(const StripParams &p, int n_seams /* of all frame
     const long n = (long)(p.strips_total - 1) * (p.row_end - p.row_begin);
     const int cb = (int)((n + 255) / 256);
     const dim3 grid((unsigned)(n_seams + cb * n_frames));
-    if (p.pre) hipLaunchKernelGGL((srcnn_seams_merged_kernel<true>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
-    else hipLaunchKernelGGL((srcnn_seams_merged_kernel<false>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
+    if (p.flag) hipLaunchKernelGGL((srcnn_seams_merged_kernel<false, true>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
+    else if (p.pre) hipLaunchKernelGGL((srcnn_seams_merged_kernel<true, false>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
+    else hipLaunchKernelGGL((srcnn_seams_merged_kernel<false, false>), grid, dim3(NTHREADS), 0, stream, p, d_seams, n_seams, d_winmap, cb);
     return hipGetLastError();
 }
 
 hipError_t launch_seams(const StripParams &p, int n_seams /* of all frames */, const int *d_seams, hipStream_t stream)
 {
-    if (p.pre) hipLaunchKernelGGL((srcnn_seam_kernel<true>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
-    else hipLaunchKernelGGL((srcnn_seam_kernel<false>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
+    if (p.flag) hipLaunchKernelGGL((srcnn_seam_kernel<false, true>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
+    else if (p.pre) hipLaunchKernelGGL((srcnn_seam_kernel<true, false>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
+    else hipLaunchKernelGGL((srcnn_seam_kernel<false, false>), dim3(n_seams), dim3(NTHREADS), 0, stream, p, d_seams);
     return hipGetLastError();
 }
 
@@ -946,7 +976,11 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
     const bool pre = p.pre != nullptr;
     switch (mode) {
     case MODE_FUSED:
-        if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
+        if (p.flag) {
+            if (pre) return hipErrorInvalidValue;       // (the API runs pre-clamp requests of that mode on the exact kernels)
+            hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, true>), grid, block, lds, stream, p);
+        }
+        else if (p.tune & 16) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 2>), grid, block, lds, stream, p);
         else if (pre) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false>), grid, block, lds, stream, p);
         break;

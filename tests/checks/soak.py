@@ -4,7 +4,9 @@
 usage: python tests/checks/soak.py [seconds] [seed]
 Random plane sizes (biased to strip / unit / item-planner boundaries), padded strides, three
 content types; every result is checked: float32 MFMA mode bitwise against the FMA-order model and
-within tolerance of the reference arithmetic, split-f16 mode within tolerance, exact mode bitwise.
+within tolerance of the reference arithmetic, split-f16 mode within tolerance, exact mode bitwise,
+REFBYTES mode (MFMA + exact fix-up of the pixels next to a truncation boundary) BYTEWISE equal to the
+reference arithmetic, with the margin its monitor reports.
 """
 import sys, time
 from pathlib import Path
@@ -40,6 +42,11 @@ while time.time() - t0 < budget:
     for name, mode in (("mfma", S.MODE_MFMA), ("split16", S.MODE_SPLIT16), ("exact", S.MODE_EXACT)):
         if name == "exact" and w * h > 200000: continue
         ctx.set_mode(mode)
+        if name == "mfma":      # ... and the same plane in REFBYTES mode: the reference's bytes, no tolerance
+            ctx.set_mode(S.MODE_REFBYTES)
+            rb = ctx.forward_y(yv)
+            assert np.array_equal(rb, r_out), ("refbytes", w, h, kind, int((rb != r_out).sum()))
+            ctx.set_mode(mode)
         pre = np.full((h, w), np.nan, np.float32)
         out = ctx.forward_y(yv, preclamp=pre)
         assert np.isfinite(pre).all(), (name, w, h)
@@ -57,5 +64,10 @@ while time.time() - t0 < budget:
             assert np.abs(r_pre - np.rint(r_pre))[d != 0].max() <= TOL * scale, (name, w, h, kind)
     n += 1
 ctx.set_mode(S.MODE_MFMA)
+st = ctx.fixup_stats()
+assert st["max_dev"] < 0.5 * st["delta"], st
+print(f"refbytes: every plane bytewise equal to the reference arithmetic; {st['scattered_pixels']} pixels recomputed one by one, "
+      f"{st['dense_tiles']} tiles whole, {st['bytes_changed']} bytes changed; largest |v_mfma - v_ref| seen {st['max_dev']:.2e} "
+      f"against delta {st['delta']:.2e}")
 print(f"soak ok: {n} random planes in {time.time() - t0:.0f} s (seed {seed}); worst pre-clamp error / max(1, |ref|max/255): "
       f"mfma {worst['mfma']:.2e}, split16 {worst['split16']:.2e}")

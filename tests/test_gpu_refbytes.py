@@ -1,0 +1,164 @@
+"""SRCNN_MODE_REFBYTES: the reference's BYTES from the MFMA path (VERDICT r02 "missing" 2).
+
+The float32 MFMA kernel differs from the reference arithmetic by rounding noise (<= 4.1e-4 before truncation), so a byte can
+differ only where the pre-truncation value lies next to an integer (src/srcnn.cpp:238-240 truncates).  In this mode the fused
+kernel flags those pixels (|v - rint(v)| <= delta, delta derived from the model: 2.0e-3 for the shipped one, ~0.4 % of the
+pixels) and two small kernels recompute exactly them -- whole 12 x 12 tiles where flat or periodic content flags a region --
+in the reference's arithmetic (csrc/srcnn_exact.hip).  Every test here compares with ``oracle.forward_y`` BIT FOR BIT: no
+tolerance anywhere in this file.
+"""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_batch, synth_luma
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+EDGE_SIZES = [(1, 1), (3, 3), (9, 5), (5, 9), (17, 4), (2, 40), (40, 2), (31, 7), (33, 9), (12, 12), (13, 25), (24, 11)]
+TILE_SIZES = [(123, 11), (124, 13), (127, 6), (128, 20), (129, 10), (249, 8), (300, 70), (97, 61), (640, 360), (1000, 333)]
+
+
+@pytest.fixture()
+def ref_ctx(weights_blob):
+    ctx = S.Context(0)
+    ctx.set_weights_blob(weights_blob)
+    ctx.set_mode(S.MODE_REFBYTES)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h", EDGE_SIZES + TILE_SIZES)
+def test_reference_bytes_on_every_size(ref_ctx, weights_blob, w, h):
+    for frame in (0, 5):
+        y = synth_luma(w, h, frame=frame)
+        assert np.array_equal(ref_ctx.forward_y(y), oracle.forward_y(y, weights_blob)[0])
+
+
+@pytest.mark.parametrize("value", [0, 1, 16, 77, 128, 200, 235, 255])
+def test_constant_planes_take_the_dense_tile_path(ref_ctx, weights_blob, value):
+    """A flat region gives ONE pre-truncation value: either no pixel of it is flagged or every one -- whole tiles are then
+    recomputed (a letterbox must not cost 25 feature positions per pixel)."""
+    y = np.full((150, 333), value, np.uint8)
+    before = ref_ctx.fixup_stats()
+    assert np.array_equal(ref_ctx.forward_y(y), oracle.forward_y(y, weights_blob)[0])
+    after = ref_ctx.fixup_stats()
+    assert after["scattered_pixels"] - before["scattered_pixels"] <= 10 * 333 * 150 // 144 + 2000   # at most 10 per tile
+
+
+def test_periodic_and_saturating_content(ref_ctx, weights_blob):
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:400, 0:700]
+    planes = {
+        "checkerboard": np.where(((yy // 8) + (xx // 8)) % 2 == 0, 16, 240).astype(np.uint8),
+        "stripes": np.where((xx // 3) % 2 == 0, 30, 220).astype(np.uint8),
+        "white noise": rng.integers(0, 256, (400, 700), dtype=np.uint8),
+        "bright ramp": np.clip(200 + xx * 55 // 700 + rng.integers(0, 4, (400, 700)), 0, 255).astype(np.uint8),
+        "letterbox": np.concatenate([np.full((60, 700), 16, np.uint8), synth_luma(700, 280, frame=2), np.full((60, 700), 16, np.uint8)]),
+    }
+    for name, y in planes.items():
+        assert np.array_equal(ref_ctx.forward_y(y), oracle.forward_y(y, weights_blob)[0]), name
+
+
+def test_full_4k_frame_has_the_oracle_sha(ref_ctx, weights_blob):
+    """The plane the MFMA mode gets 259 bytes 'wrong' (tests/golden/synthetic_4k_checksums.json): here sha256 == the
+    reference arithmetic's, and the statistics say what it took."""
+    pin = json.loads((GOLD / "synthetic_4k_checksums.json").read_text())
+    y = synth_luma(3840, 2160)
+    assert hashlib.sha256(y.tobytes()).hexdigest() == pin["input_sha256"]
+    before = ref_ctx.fixup_stats()
+    out = ref_ctx.forward_y(y)
+    st = ref_ctx.fixup_stats()
+    assert hashlib.sha256(out.tobytes()).hexdigest() == pin["oracle_sha256"]
+    flagged = st["scattered_pixels"] - before["scattered_pixels"]
+    changed = st["bytes_changed"] - before["bytes_changed"]
+    assert 0.002 * y.size < flagged < 0.008 * y.size            # ~2 delta of the pixels
+    assert changed == pin["u8_mismatches_between_them"]         # exactly the bytes the MFMA mode differs on
+    assert 0 < st["max_dev"] < 0.5 * st["delta"], st            # the margin: |v_mfma - v_ref| seen on the flagged sample
+    assert abs(st["delta"] - 2.0e-3) < 1e-4
+
+
+def test_batches_stripes_and_device_entry_points(ref_ctx, weights_blob):
+    import torch
+    w, h, n = 1920, 1080, 5
+    frames = synth_batch(w, h, n, first_frame=20)
+    want = [oracle.forward_y(f, weights_blob)[0] for f in frames]
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ref_ctx.forward_y_dev(d_in.data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, w, h, n)
+    ref_ctx.synchronize()
+    got = d_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(got[k], want[k]), k
+    # host frame stream (two lanes, overlapped transfers)
+    streamed = ref_ctx.forward_y_frames(frames)
+    assert all(np.array_equal(streamed[k], want[k]) for k in range(n))
+    # row stripes of frame 0, each from its own halo-extended rows, thin and odd ones included
+    out = np.zeros_like(frames[0])
+    bounds = [0, 7, 200, 201, 540, 1073, h]
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        s0, s1 = max(0, r0 - 6), min(h, r1 + 6)
+        d_s = torch.from_numpy(np.ascontiguousarray(frames[0][s0:s1])).cuda()
+        d_o = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ref_ctx.forward_y_rows_dev(d_s.data_ptr(), w, s0, d_o.data_ptr(), w, r0, w, h, r0, r1)
+        ref_ctx.synchronize()
+        out[r0:r1] = d_o.cpu().numpy()
+    assert np.array_equal(out, want[0])
+    # strided planes
+    d_big = torch.zeros((h, w + 96), dtype=torch.uint8, device="cuda")
+    d_big[:, :w] = d_in[1]
+    d_bo = torch.full((h, w + 160), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ref_ctx.forward_y_dev(d_big.data_ptr(), w + 96, 0, d_bo.data_ptr(), w + 160, 0, w, h, 1)
+    ref_ctx.synchronize()
+    res = d_bo.cpu().numpy()
+    assert np.array_equal(res[:, :w], want[1]) and (res[:, w:] == 9).all()
+
+
+def test_preclamp_request_gets_the_reference_float(ref_ctx, weights_blob):
+    y = synth_luma(300, 70, frame=1)
+    pre = np.empty(y.shape, np.float32)
+    out = ref_ctx.forward_y(y, preclamp=pre)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    assert np.array_equal(out, r_out) and np.array_equal(pre, r_pre)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_models_scale_their_threshold(seed):
+    """delta follows the model (6 * 2^-24 * ||W3|| * bound of the layer-2 map): other weights, other magnitudes, same result --
+    the reference's bytes."""
+    rng = np.random.default_rng(seed)
+    w1 = (rng.standard_normal(5184) * 0.12).astype(np.float32)
+    b1 = (rng.standard_normal(64) * 20 + 10).astype(np.float32)
+    w2 = (rng.standard_normal(2048) * 0.15 * seed).astype(np.float32)
+    b2 = (rng.standard_normal(32) * 10).astype(np.float32)
+    w3 = (rng.standard_normal(800) * 0.02).astype(np.float32)
+    b3 = np.float32(20.0)
+    blob = np.concatenate([b1, w1, b2, w2, [b3], w3]).astype(np.float32)
+    y = synth_luma(500, 260, frame=seed)
+    with S.Context(0) as ctx:
+        ctx.set_weights(w1, b1, w2, b2, w3, b3)
+        ctx.set_mode(S.MODE_REFBYTES)
+        out = ctx.forward_y(y)
+        st = ctx.fixup_stats()
+    assert np.array_equal(out, oracle.forward_y(y, blob)[0])
+    assert st["max_dev"] < 0.5 * st["delta"], st
+
+
+def test_pipeline_reproduces_the_reference_picture(weights_blob):
+    """BGR in, BGR out (src/srcnn.cpp:505-659) in REFBYTES mode: the reference's own butterfly-srcnn.png, all 995,328 bytes --
+    what only SRCNN_MODE_EXACT did before, at a third of the speed."""
+    fx = np.load(GOLD / "butterfly_bgr.npz")
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        ctx.set_mode(S.MODE_REFBYTES)
+        out = ctx.process_bgr(fx["src_bgr"], 1.5)
+    assert np.array_equal(out, fx["ref_bgr"])
