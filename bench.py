@@ -173,11 +173,13 @@ def launch_ranks(n: int, cmd=None) -> int:
     reader.join(timeout=5)
     for sig, h in old_handlers.items():
         signal.signal(sig, h)
+    if failed is None:                               # (every rank may have exited between two polls)
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        failed = bad[0] if bad else None
     if failed is None:
         sys.stdout.write((out0[0] if out0 else b"").decode())
         sys.stdout.flush()
-        bad = [p.returncode for p in procs if p.returncode != 0]
-        return bad[0] if bad else 0
+        return 0
     return failed[1] if 0 < failed[1] < 256 else 1
 
 

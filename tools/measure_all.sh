@@ -18,6 +18,10 @@ run --steps 10 --path surface-dev                              # the same two ca
 run --steps 20 --width 1920 --height 1080                       # a 1080p plane
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode
+run --steps 30 --mode refbytes                                  # the reference's bytes: MFMA kernel + exact fix-up of flagged pixels
+run --steps 5 --mode refbytes --frames 64                       # ... 64 x 3840x2160
+run --steps 20 --mode refbytes --width 1920 --height 1080       # ... a 1080p plane
+run --steps 20 --mode refbytes --path pipeline                  # ... BGR 1080p -> BGR 4K
 run --steps 50 --mode split16                                   # opt-in split-f16 mode, 1 x 3840x2160
 run --steps 5 --mode split16 --frames 64                        # opt-in split-f16 mode, 64 x 3840x2160
 run --steps 20 --mode split16 --path pipeline                   # BGR 1080p -> BGR 4K with the split-f16 conv path

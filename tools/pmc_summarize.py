@@ -135,12 +135,12 @@ with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
 
 # per-kernel averages of the other runs (rocprofv3 --stats): OUTDIR/other_kernels_stats.csv
 rows = [["run", "kernel", "calls", "avg_us"]]
-for tag in ("unfused", "pipeline", "exact", "pipeline_split16"):
+for tag in ("unfused", "pipeline", "exact", "pipeline_split16", "refbytes"):
     for f in glob.glob(os.path.join(out, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in list(csv.reader(fh))[1:]:
                 if "srcnn::" in r[0]:
-                    name = r[0].replace("void ", "").split("(srcnn::StripParams")[0].split("(unsigned char")[0].split("(float")[0]
+                    name = r[0].replace("void ", "").split("(srcnn::StripParams")[0].split("(srcnn::FixParams")[0].split("(unsigned char")[0].split("(float")[0]
                     rows.append([tag, name, r[1], f"{float(r[3]) / 1000:.1f}"])
 if len(rows) > 1:
     with open(os.path.join(out, "other_kernels_stats.csv"), "w", newline="") as fh:

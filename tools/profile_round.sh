@@ -10,6 +10,9 @@ ROOT=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2>> $OUT/bench_default.err      # the driver's exact command
+python bench.py --mode refbytes --no-cpu-baseline > $OUT/bench_refbytes.json 2>> $OUT/bench_default.err
+python bench.py --mode refbytes --frames 64 --steps 5 --no-cpu-baseline > $OUT/bench_refbytes_b64.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --no-cpu-baseline > $OUT/bench_split16.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --frames 64 --steps 10 --no-cpu-baseline > $OUT/bench_split16_b64.json 2>> $OUT/bench_default.err
 for mode in mfma split16; do
@@ -30,7 +33,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU 
       python3 $ROOT/bench.py --path unfused --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ) > $OUT/pmc_unfused_$tag.log 2>&1
 done
 # the other kernels: unfused path (layer-1/2 kernel + layer-3 kernel), pipeline byte kernels, exact kernels
-for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20"; do
+for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20" "refbytes --mode refbytes --steps 20"; do
   set -- $cfg; tag=$1; shift
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$tag -o trace -- \
       python3 $ROOT/bench.py "$@" --warmup 1 --no-cpu-baseline ) > $OUT/trace_$tag.log 2>&1
@@ -40,6 +43,9 @@ python tools/diag_light.py > $OUT/diag_light_4k.txt 2>&1
 python tools/diag_light.py 7680 4320 > $OUT/diag_light_8k.txt 2>&1
 python tools/evt_test.py > $OUT/clock_ramp.txt 2>&1
 python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
+tools/stripe_overhead.sh $OUT/stripe_overhead.txt > /dev/null 2>&1
+python tests/checks/soak.py 120 31 > $OUT/soak.txt 2>&1
+python tests/checks/soak_paths.py 60 37 > $OUT/soak_paths.txt 2>&1
 python tests/checks/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
 python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
 [ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
