@@ -2526,6 +2526,31 @@ int srcnn_debug_pack_fragments(const float *blob8129, float *frag /*[NFRAG*64]*/
     return split16_range_ok(w1, b1, w2, b2, w3) ? 1 : 0;
 }
 
+/* Undocumented test hook (needs no device): the persistent worker threads of the several-GPUs entry points.  `rounds` calls of
+ * run() over n "contexts", growing from 1 to n; every task must run exactly once per call, on its own thread for k > 0, and the
+ * first non-zero code must come back.  Returns 0 when all of that held. */
+int srcnn_debug_worker_pool(int n, int rounds)
+{
+    if (n < 1 || n > 64 || rounds < 1) return SRCNN_ERR_INVALID;
+    WorkerPool pool;
+    std::vector<long> hits((size_t)n, 0);
+    for (int r = 0; r < rounds; ++r) {
+        const int m = 1 + r % n;
+        const int fail_at = (r % 7 == 3 && m > 1) ? m - 1 : -1;
+        const int rc = pool.run(m, [&](int k) -> int {
+            ++hits[(size_t)k];                       // each k is touched by one thread per call: no race
+            return k == fail_at ? -100 - k : 0;
+        });
+        if (rc != (fail_at >= 0 ? -100 - fail_at : 0)) return -1;
+    }
+    for (int k = 0; k < n; ++k) {
+        long want = 0;
+        for (int r = 0; r < rounds; ++r) want += (1 + r % n) > k;
+        if (hits[(size_t)k] != want) return -2;
+    }
+    return pool.size() == n - 1 ? 0 : -3;
+}
+
 int srcnn_debug_cubic_table(int n_src, int n_dst, int *ofs, short *coef)
 {
     if (n_src <= 0 || n_dst <= 0 || !ofs || !coef) return SRCNN_ERR_INVALID;

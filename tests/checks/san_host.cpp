@@ -19,6 +19,8 @@ hipError_t launch_seams(const StripParams &, int, const int *, hipStream_t) { re
 hipError_t launch_cseams(const StripParams &, int, hipStream_t) { return never(); }
 hipError_t launch_seams_merged(const StripParams &, int, const int *, const unsigned char *, int, hipStream_t) { return never(); }
 hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
+hipError_t launch_fixup(const FixParams &, int, hipStream_t) { return never(); }
+size_t fixup_list_entries(int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv11_exact(const float *, long, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
@@ -37,6 +39,7 @@ int srcnn_debug_plan_items(int n_cu, int n_strips, int row_begin, int row_end, i
                            int *items, int max_items, int *seams, int max_seams, int *n_seams);
 int srcnn_debug_pack_fragments(const float *blob8129, float *frag, uint8_t *frag16, int *frag_floats, int *frag16_bytes);
 int srcnn_debug_cubic_table(int n_src, int n_dst, int *ofs, short *coef);
+int srcnn_debug_worker_pool(int n, int rounds);
 int srcnn_stripe_rows(int height, int n_parts, int index, int *row_begin, int *row_end);
 int srcnn_scaled_size(int width, int height, float scale, int *out_w, int *out_h);
 }
@@ -48,6 +51,15 @@ int srcnn_scaled_size(int width, int height, float scale, int *out_w, int *out_h
 
 int main(int argc, char **argv)
 {
+    // ---- the persistent worker threads of the several-GPUs entry points (condition variables, task hand-over, teardown) ----
+    CHECK(srcnn_debug_worker_pool(1, 5) == 0);
+    CHECK(srcnn_debug_worker_pool(8, 2000) == 0);
+    CHECK(srcnn_debug_worker_pool(3, 301) == 0);
+#ifdef SRCNN_SAN_POOL_ONLY      // the ThreadSanitizer pass: the pool is the only threaded host code
+    std::printf("ok: worker pool\n");
+    return 0;
+#endif
+
     // ---- planner: exact-size buffers (one int beyond them is a sanitizer error), every geometry class ----
     long plans = 0, with_items = 0;
     for (int n_cu : {1, 4, 64, 256, 304})

@@ -117,3 +117,15 @@ def test_seam_windows_of_neighbouring_strips_stay_apart():
         for s in range(n_strips):                      # ... and inside a strip two seams are at least an item apart
             b = np.sort(se[se[:, 0] == s][:, 1])
             assert (np.diff(b) >= 10).all()
+
+
+def test_worker_pool_of_the_multi_gpu_entry_points():
+    """srcnn_forward_y_striped* / srcnn_forward_y_frames_multi park one persistent host thread per context beyond the first
+    between calls (no thread spawn per step).  The hook runs thousands of rounds over a growing number of workers: every task
+    exactly once per call, the first non-zero code returned, n - 1 threads in all.  (ASan / UBSan: tests/test_sanitizers.py.)"""
+    import srcnn_cpp_amd as S
+    lib = S.load_library()
+    lib.srcnn_debug_worker_pool.restype = int
+    assert lib.srcnn_debug_worker_pool(8, 3000) == 0
+    assert lib.srcnn_debug_worker_pool(1, 10) == 0
+    assert lib.srcnn_debug_worker_pool(0, 1) == -1

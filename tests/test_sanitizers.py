@@ -31,6 +31,21 @@ def test_host_logic_under_asan_ubsan(tmp_path):
     assert r.stdout.startswith("ok:") and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
 
 
+def test_worker_pool_under_thread_sanitizer(tmp_path):
+    """The persistent worker threads of the several-GPUs entry points (WorkerPool in srcnn_api.cpp: one mutex + condition
+    variable per worker, tasks handed over and results collected per call) under ThreadSanitizer: a data race or a lost wake-up
+    in that hand-over would be a wrong row stripe once in a million steps.  The same harness, SRCNN_SAN_POOL_ONLY: only the pool."""
+    exe = tmp_path / "tsan_host"
+    subprocess.run([str(CLANG), "-fsanitize=thread", "-g", "-O1", "-std=c++17", "-DSRCNN_SAN_POOL_ONLY", "-D__HIP_PLATFORM_AMD__",
+                    "-I/opt/rocm/include", f"-I{ROOT / 'srcnn_cpp_amd' / 'csrc'}", str(ROOT / "srcnn_cpp_amd" / "csrc" / "srcnn_api.cpp"),
+                    str(ROOT / "tests" / "checks" / "san_host.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
+                    "-pthread", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env={"PATH": "/usr/bin:/bin", "TSAN_OPTIONS": "halt_on_error=1"},
+                       timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith("ok: worker pool"), (r.stdout + r.stderr)[-3000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
 def png_chunk(kind: bytes, body: bytes) -> bytes:
     return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
 
