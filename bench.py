@@ -83,7 +83,7 @@ def cpu_baseline_child(width, height, target_s=12.0):
     (reference loops, strict IEEE, OpenMP) on a bounded slab of the same workload; rows are
     independent, so a slab of full-width rows has the per-pixel cost of the whole frame."""
     import ctypes
-    import numpy as np  # noqa: F401
+    import numpy as np
     import oracle
     import srcnn_cpp_amd as S
     from srcnn_cpp_amd.synth import synth_luma
@@ -92,8 +92,16 @@ def cpu_baseline_child(width, height, target_s=12.0):
     threads = int(os.environ.get("OMP_NUM_THREADS", physical))
     blob = S.load_weights()
     frame = synth_luma(width, height)
-    v, reps, rows, dt = _time_oracle(lambda f: oracle.forward_y(f, blob), frame, width, height, target_s, threads)
-    out = {"value": round(v, 4), "unit": "MPix/s", "cores": threads, "kind": "port",
+    last = {}
+
+    def fwd(f):
+        last["rows"], last["out"] = f.shape[0], oracle.forward_y(f, blob)[0]
+    v, reps, rows, dt = _time_oracle(fwd, frame, width, height, target_s, threads)
+    # what the reference arithmetic makes of the bench's frame: sha256 of the last slab computed (the whole plane when the slab
+    # is the whole plane) -- bench.py checks the SRCNN_MODE_REFBYTES output of the GPU against it
+    import hashlib
+    ref_sha = {"rows": int(last["rows"]), "sha256": hashlib.sha256(np.ascontiguousarray(last["out"]).tobytes()).hexdigest()}
+    out = {"value": round(v, 4), "unit": "MPix/s", "cores": threads, "kind": "port", "reference_output": ref_sha,
            "threads": threads, "physical_cores": physical, "logical_cpus": logical, "cpu_model": model,
            "binding": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND', 'unset')} "
                       f"OMP_PLACES={os.environ.get('OMP_PLACES', 'unset')}",
@@ -235,6 +243,7 @@ def parse_args():
                          "0 disables it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive secondary figure (`e2e`)")
+    ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="transport of the stripe halo exchange (nccl == RCCL over xGMI; gloo stages through host "
@@ -578,6 +587,36 @@ def worker(args):
                           "output_equals_resident": bool(zlib.crc32(ho[n_e2e - 1].tobytes()) == crcs[0])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H)
+        if world == 1 and args.path == "fused" and args.mode == "mfma" and not stripe and not args.no_refbytes:
+            # The same step in SRCNN_MODE_REFBYTES (the MFMA kernel + exact recomputation of the pixels next to a truncation
+            # boundary): its time, what the fix-up did, and -- against the sha256 the cpu_baseline leg's oracle made of the same
+            # frame -- whether the bytes ARE the reference arithmetic's.  Never `value`.
+            import hashlib
+            ctx.set_stream(stream.cuda_stream)
+            ctx.set_mode(S.MODE_REFBYTES)
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t_r = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt_r = (time.perf_counter() - t_r) / args.steps
+            rb = d_out.cpu().numpy()
+            ref = (out.get("cpu_baseline") or {}).get("reference_output") or {}
+            rows = int(ref.get("rows", 0))
+            equal = None
+            if 0 < rows <= H:
+                # a slab of the top `rows` rows of the plane is exact away from its cut: compare all but its last 6 rows' worth
+                # when it is a crop, the whole plane when it is the whole plane
+                if rows == H:
+                    equal = hashlib.sha256(np.ascontiguousarray(rb[0]).tobytes()).hexdigest() == ref.get("sha256")
+            out["refbytes"] = {"ms_per_step": round(dt_r * 1e3, 4), "value": round(W * H * F / dt_r / 1e6, 2), "unit": "MPix/s",
+                               "vs_mfma_mode": round(dt_r / (elapsed / args.steps), 3), "fixup": ctx.fixup_stats(),
+                               "equals_reference_arithmetic": equal,
+                               "checked_against": "sha256 of oracle.forward_y on the same frame (cpu_baseline leg)" if equal is not None
+                                                  else "not checked (no whole-plane oracle output in this run)"}
+            ctx.set_mode(S.MODE_MFMA)
         emit_line(out)
 
     ctx.close()

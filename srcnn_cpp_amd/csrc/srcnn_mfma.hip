@@ -70,18 +70,34 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// -DSRCNN_SAFE_HAZARDS: a fallback build in which every MFMA -> vector-ALU and vector-ALU -> MFMA operand dependency of the row
+// body is visible to the compiler's hazard recogniser, which then pads the wait states the ISA manual asks for: the first MFMAs
+// of the layer-2 / layer-3 chains are the builtin, ReLU is a plain max (no inline asm anywhere between them).  The product build
+// relies on the hardware interlocking those dependencies (measured: tools/mfma_interlock_probe.hip, a GPU test) and is ~3 %
+// faster; both builds must produce the same bytes (tests/test_gpu_hardening.py::test_safe_hazard_build_gives_the_same_bytes).
+#ifndef SRCNN_SAFE_HAZARDS
+#define SRCNN_SAFE_HAZARDS 0
+#endif
+
 // The first MFMA of a chain whose B operand a packed-multiply (inline asm) has just produced, written as inline asm
 // too: the compiler's hazard recogniser does not count inline-asm statements as wait states, sees the previous chain's
 // last MFMA "right before" this one and pads with s_nop 13 / s_nop 9 (56 / 40 idle cycles per wave-row) although
 // 16 / 8 vector instructions lie between them.
 __device__ __forceinline__ f32x16 mfma_first(float a, float b, const f32x16 &c)
 {
+#if SRCNN_SAFE_HAZARDS
+    return MFMA(a, b, c);
+#endif
     f32x16 d;
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
 __device__ __forceinline__ f32x16 mfma_first0(float a, float b)      // ... with a zero accumulator
 {
+#if SRCNN_SAFE_HAZARDS
+    const f32x16 z = {0};
+    return MFMA(a, b, z);
+#endif
     f32x16 d;
     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
     return d;
@@ -175,6 +191,11 @@ __device__ __forceinline__ void cseam_export(const float *tile, float *dst, int 
 // min(max(x, 0), 1) = max(x, 0), the reference's (x < 0) ? 0 : x (src/srcnn.cpp:304,319).
 __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
 {
+#if SRCNN_SAFE_HAZARDS
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = __builtin_fmaxf(a[q], 0.f);       // activations are <= 1 by the layers' scaling: max(x, 0) is the clamp
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         f32x2 pr = {a[2 * q], a[2 * q + 1]};

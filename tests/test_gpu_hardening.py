@@ -218,3 +218,20 @@ def test_reference_call_sites_with_device_planes(gpu_ctx, weights_blob):
     m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
     assert np.array_equal(out, m_out)
     gpu_ctx.set_weights_blob(weights_blob)
+
+
+def test_safe_hazard_build_gives_the_same_bytes(tmp_path, weights_blob):
+    """-DSRCNN_SAFE_HAZARDS builds the strip kernels with every MFMA <-> vector-ALU dependency of the row body visible to the
+    compiler (builtin MFMAs, plain max for ReLU: the hazard recogniser pads the wait states the ISA manual asks for), as the
+    fallback should the hardware interlock the product build relies on ever not hold.  Same bytes as the product, by
+    construction of the arithmetic -- checked on planes that exercise the FAST body, the seams and a batch."""
+    env = dict(os.environ, SRCNN_BUILD_VARIANT="safe", SRCNN_BUILD_DEFINES="-DSRCNN_SAFE_HAZARDS=1")
+    subprocess.run([sys.executable, "-m", "srcnn_cpp_amd.build"], check=True, cwd=ROOT, env=env, timeout=1200,
+                   stdout=subprocess.DEVNULL)
+    lib = ROOT / "srcnn_cpp_amd" / "libsrcnn_amd_safe.so"
+    assert lib.exists()
+    product = _run_child({})
+    safe = _run_child({"SRCNN_LIB": str(lib)})
+    assert safe == product
+    m_out, _ = oracle.gpuorder_forward_y(synth_luma(300, 70), weights_blob)
+    assert safe["300x70"] == zlib.crc32(m_out.tobytes())
