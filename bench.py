@@ -572,7 +572,7 @@ def worker(args):
         if world == 1 and args.path == "fused" and not stripe and not args.no_e2e:
             # SURVEY 8d's secondary metric, never `value`: the same planes from and to HOST memory, PCIe-inclusive
             # (srcnn_forward_y_frames: pinned staging, uploads / kernels / downloads of neighbouring frames overlapped).
-            n_e2e = 8
+            n_e2e = 16                                         # (fill and drain of the two-lane pipeline are 0.6 ms: 7 % of 8 frames)
             hf = np.ascontiguousarray(np.broadcast_to(frames[0], (n_e2e,) + frames[0].shape))
             ho = np.empty_like(hf)
             ctx.set_stream(0)                                  # the context's own stream

@@ -1861,10 +1861,9 @@ int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_s
         c->pin_cap = n;
     }
     hipStream_t caller = c->stream;
-    auto rows_copy = [&](uint8_t *d, size_t ds, const uint8_t *sp, size_t ss) {
-        if (ds == (size_t)width && ss == (size_t)width) std::memcpy(d, sp, n);
-        else for (int r = 0; r < height; ++r) std::memcpy(d + (size_t)r * ds, sp + (size_t)r * ss, (size_t)width);
-    };
+    // (between the caller's pageable memory and the pinned staging on a few host threads: one thread moves 16.6 MB per
+    // 3840x2160 frame -- in and out -- in about the time the kernel takes, and the stream becomes host-bound)
+    auto rows_copy = [&](uint8_t *d, size_t ds, const uint8_t *sp, size_t ss) { copy_rows_mt<uint8_t>(d, ds, sp, ss, width, height); };
     auto finish = [&](int i) -> hipError_t {           // wait for frame i's lane, hand the plane to the caller
         const int k = i & 1;
         hipError_t e = hipStreamSynchronize(c->lane_stream[k]);
@@ -2331,7 +2330,7 @@ hipError_t copy_rows_between(srcnn_ctx *to, uint8_t *dst, size_t dst_stride, con
                              size_t src_stride, int width, int rows, hipStream_t st)
 {
     if (from->device == to->device)
-        return hipMemcpy2DAsync(dst, dst_stride, src, src_stride, (size_t)width, (size_t)rows, hipMemcpyDeviceToDevice, st);
+        return launch_copy_rows(dst, (long)dst_stride, src, (long)src_stride, width, rows, st);
     if (dst_stride == (size_t)width && src_stride == (size_t)width)
         return hipMemcpyPeerAsync(dst, to->device, src, from->device, (size_t)width * rows, st);
     for (int r = 0; r < rows; ++r) {
@@ -2380,8 +2379,7 @@ int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const 
         if (has_top)
             HIP_TRY(c, copy_rows_between(c, ext, width, ctxs[k - 1], d_stripes[k - 1] + (size_t)(a1 - a0 - kHalo) * stripe_stride,
                                          stripe_stride, width, kHalo, c->halo_stream));
-        HIP_TRY(c, hipMemcpy2DAsync(ext + (size_t)(r0 - s0) * width, width, d_stripes[k], stripe_stride, width, rows,
-                                    hipMemcpyDeviceToDevice, c->halo_stream));
+        HIP_TRY(c, launch_copy_rows(ext + (size_t)(r0 - s0) * width, width, d_stripes[k], (long)stripe_stride, width, rows, c->halo_stream));
         if (has_bot)
             HIP_TRY(c, copy_rows_between(c, ext + (size_t)(r1 - s0) * width, width, ctxs[k + 1], d_stripes[k + 1], stripe_stride,
                                          width, kHalo, c->halo_stream));
@@ -2397,12 +2395,11 @@ int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const 
     if (has_top) {
         HIP_TRY(c, copy_rows_between(c, top, width, ctxs[k - 1], d_stripes[k - 1] + (size_t)(a1 - a0 - kHalo) * stripe_stride,
                                      stripe_stride, width, kHalo, c->halo_stream));
-        HIP_TRY(c, hipMemcpy2DAsync(top + (size_t)kHalo * width, width, d_stripes[k], stripe_stride, width, 2 * kHalo,
-                                    hipMemcpyDeviceToDevice, c->halo_stream));
+        HIP_TRY(c, launch_copy_rows(top + (size_t)kHalo * width, width, d_stripes[k], (long)stripe_stride, width, 2 * kHalo, c->halo_stream));
     }
     if (has_bot) {
-        HIP_TRY(c, hipMemcpy2DAsync(bot, width, d_stripes[k] + (size_t)(rows - 2 * kHalo) * stripe_stride, stripe_stride, width,
-                                    2 * kHalo, hipMemcpyDeviceToDevice, c->halo_stream));
+        HIP_TRY(c, launch_copy_rows(bot, width, d_stripes[k] + (size_t)(rows - 2 * kHalo) * stripe_stride, (long)stripe_stride, width,
+                                    2 * kHalo, c->halo_stream));
         HIP_TRY(c, copy_rows_between(c, bot + (size_t)2 * kHalo * width, width, ctxs[k + 1], d_stripes[k + 1], stripe_stride,
                                      width, kHalo, c->halo_stream));
     }

@@ -165,6 +165,7 @@ hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, lon
                                hipStream_t st);
 
 // ---- pipeline steps around the conv path (srcnn_pipeline.hip) ---------------
+hipError_t launch_copy_rows(uint8_t *dst, long dstride, const uint8_t *src, long sstride, int width, int rows, hipStream_t st);
 hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,
                             long ppitch, hipStream_t st);
 hipError_t launch_ycrcb2bgr(const uint8_t *y, long ystride, const uint8_t *crcb, long pstride, long ppitch, int w,

@@ -403,6 +403,31 @@ hipError_t launch_resize_merge(const uint8_t *bgr, long stride, int sw, int sh, 
     return hipGetLastError();
 }
 
+// A few rows of a byte plane, device to device on ONE device, as a kernel: the striped step's band assembly (12 + 12 rows per
+// step).  A launch is queued like the kernels around it and never blocks the host; hipMemcpy2DAsync between device buffers was
+// seen to, once a process keeps more streams busy than the device has hardware queues (profiles/r03/stripe_overhead.txt).
+__global__ __launch_bounds__(256) void copy_rows_kernel(uint8_t *__restrict__ dst, long dstride, const uint8_t *__restrict__ src,
+                                                        long sstride, int width)
+{
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= width) return;
+    const uint8_t *s = src + (long)blockIdx.y * sstride + x;
+    uint8_t *d = dst + (long)blockIdx.y * dstride + x;
+    if (x + 4 <= width && (((size_t)s | (size_t)d) & 3) == 0) {
+        *reinterpret_cast<unsigned *>(d) = *reinterpret_cast<const unsigned *>(s);
+    } else {
+        for (int b = 0; b < 4 && x + b < width; ++b) d[b] = s[b];
+    }
+}
+
+hipError_t launch_copy_rows(uint8_t *dst, long dstride, const uint8_t *src, long sstride, int width, int rows, hipStream_t st)
+{
+    if (width <= 0 || rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((width + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, dst, dstride, src,
+                       sstride, width);
+    return hipGetLastError();
+}
+
 hipError_t launch_bgr2ycrcb(const uint8_t *bgr, long stride, int w, int h, uint8_t *planes, long pstride,
                             long ppitch, hipStream_t st)
 {
