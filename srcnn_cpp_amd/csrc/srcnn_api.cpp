@@ -254,11 +254,11 @@ int scale_exponent(double bound)
 // SRCNN_MODE_REFBYTES flags a pixel for exact recomputation when the MFMA path's pre-truncation value v lies within delta of
 // an integer.  delta has to exceed |v_mfma - v_ref|, the difference of two float32 evaluations of the same sums in different
 // orders with different roundings -- rounding NOISE: a rigorous worst-case bound (every rounding error at its maximum, all of
-// one sign) is ~10 grey levels and useless, the measured maximum over 18 MPix of varied content is 4.1e-4 with a tail that
+// one sign) is ~10 grey levels and useless, the measured maximum over 54 MPix of varied content is 4.4e-4 with a tail that
 // falls by a factor of 100 per 0.9e-4 (profiles/r03/fixup_margin.txt).  The noise scales with the magnitudes the model can
 // produce, so delta is tied to the model, not to a constant: E0 = 2^-24 * ||W3||_2 * B2 (one half-ulp rounding error of a
 // layer-2 activation at its rigorous bound B2, carried through the 800 layer-3 weights as independent errors) is 3.3e-4 for the
-// shipped model -- the scale of the measured maximum -- and delta = 6 * E0 = 2.0e-3: ~5 x the largest difference ever seen,
+// shipped model -- the scale of the measured maximum -- and delta = 6 * E0 = 2.0e-3: 4.5 x the largest difference ever seen,
 // 0.4 % of the pixels flagged.  fix_apply_kernel records the largest |v_mfma - v_ref| it meets (srcnn_fixup_stats), so the margin
 // of a deployment can be watched; tests/test_gpu_refbytes.py asserts it stays below delta / 2.
 float fixup_delta(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3)

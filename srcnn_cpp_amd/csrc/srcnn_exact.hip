@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
 }
 
 // ---- SRCNN_MODE_REFBYTES: the reference's bytes at (nearly) MFMA speed ------------------------------------------------
-// The MFMA path's pre-truncation value v differs from the reference's by rounding noise (measured <= 4.1e-4 on 18 MPix of
+// The MFMA path's pre-truncation value v differs from the reference's by rounding noise (measured <= 4.4e-4 on 54 MPix of
 // varied content, profiles/r03/fixup_margin.txt), so its byte can differ from the reference's only where v lies within
 // that distance of an integer -- the store truncates (src/srcnn.cpp:238-240).  The fused strip kernel therefore writes,
 // beside every output byte, a FLAG byte: 0, or a code 1..254 for (v - rint(v)) in [-delta, +delta] (StripParams::flag,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the fixed cost of a single-plane launch goes: four wall-clock stamps per wave (s_memrealtime, 100 MHz) of the
-production fused launch (SRCNN_DEBUG_TUNE=16: entry, loop start, loop end, exit) -- no per-row stamps, so the timing is
-that of the shipped kernel.  usage: tools/diag_light.py [W H]"""
+production fused launch (SRCNN_DEBUG_TUNE=16: entry, loop start, loop end, exit) -- no per-row stamps, and the stamped
+instantiation runs the same FAST row body as the shipped kernel (since round 3), so the timing is the shipped kernel's.  usage: tools/diag_light.py [W H]"""
 import ctypes, os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
