@@ -539,12 +539,16 @@ struct ItemPlan {
 // `cu_speed` (optional, one factor per CU) scales the estimate per CU.  It is not used in production: feeding back the
 // per-XCD finish times of earlier launches was tried and made things worse -- which XCD runs 1-2 % slow changes from
 // launch to launch (profiles/r02/ablation.txt).  Placement only affects speed: any plan computes the same plane.
-double kPairFast = 6.85, kPairSlow = 8.35, kAlone = 4.3, kStartFast = 3.0, kStartSlow = 7.2;   // us
+// (round 3: least-squares fit of this model to the finish times of 4,096 CUs over 16 stamped launches with different row splits,
+// profiles/r03/planner_fit.txt -- rms 6.7 us, of which launch-to-launch and per-XCD noise is most; round 2's constants were
+// 6.85 / 8.35 / 4.3 / 3.0 / 7.2 and left 247..254 rows per CU where these leave 251..254)
+double kPairFast = 6.40, kPairSlow = 8.40, kAlone = 3.76, kStartFast = 3.63, kStartSlow = 5.44;   // us
 
 double cu_finish_estimate(int fast_rows, int slow_rows, double speed)
 {
     static const bool once = [] {
-        if (const char *e = std::getenv("SRCNN_DEBUG_RATES")) std::sscanf(e, "%lf,%lf,%lf", &kPairFast, &kPairSlow, &kAlone);   // experiment knob
+        if (const char *e = std::getenv("SRCNN_DEBUG_RATES"))      // experiment knob: "fast,slow,alone[,start_fast,start_slow]"
+            std::sscanf(e, "%lf,%lf,%lf,%lf,%lf", &kPairFast, &kPairSlow, &kAlone, &kStartFast, &kStartSlow);
         return true;
     }();
     (void)once;

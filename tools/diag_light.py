@@ -60,6 +60,14 @@ for j in list(order[:12]) + list(order[-6:]):
     v = by[keys[j]]
     desc = "  ".join(f"({b}, s{int(strip_ys[b]) & 0xffffffff}, y{int(strip_ys[b]) >> 32}, {rows[4 * b]}r, {((loop1 - loop0)[4 * b] / max(1, rows[4 * b])):.2f}, {fin_blk[b]:.0f})" for b in v)
     print(f"  {fin_cu[j]:7.1f} | xcc {keys[j] >> 12} | {desc}")
+if os.environ.get("DIAG_DUMP"):      # per-CU table for fitting the planner's model: rows and times of the two workgroups of every CU
+    with open(os.environ["DIAG_DUMP"], "a") as fh:
+        for k, v in by.items():
+            if len(v) != 2:
+                continue
+            f, s2 = (v[0], v[1]) if v[0] < v[1] else (v[1], v[0])       # first-dispatched block, the one that joined it
+            fh.write(f"{W} {H} {k >> 12} {rows[4 * f]} {rows[4 * s2]} {loop0.reshape(nb, 4)[f].max():.2f} {fin_blk[f]:.2f} "
+                     f"{loop0.reshape(nb, 4)[s2].max():.2f} {fin_blk[s2]:.2f} {f} {s2}\n")
 xc = np.array([k >> 12 for k in keys])
 print("per-XCC median CU finish:", {int(x): round(float(np.median(fin_cu[xc == x])), 1) for x in np.unique(xc)})
 print(f"rows per CU: min {rows_cu.min()} max {rows_cu.max()};  loop us/row by CU pair total: median {np.median(fin_cu / rows_cu * 2):.3f}")
