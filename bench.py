@@ -223,7 +223,7 @@ def parse_args():
                          "(what include/srcnn_amd.hpp's Convolution99x11 / Convolution55 call), 32 f32 planes over PCIe; "
                          "surface-dev: the same two calls with the 32 planes kept in device memory between them "
                          "(srcnn_conv99x11_to_dev + srcnn_conv55_from_dev, the DevicePlane<float> overloads): only the u8 planes cross PCIe")
-    ap.add_argument("--mode", choices=["mfma", "exact", "split16", "refbytes"], default="mfma",
+    ap.add_argument("--mode", choices=["mfma", "exact", "split16", "refbytes", "refbytes16"], default="mfma",
                     help="mfma: float32 MFMA (default, the headline); exact: reference arithmetic on the vector ALU; "
                          "refbytes: the float32 MFMA kernel + exact recomputation of the ~0.4 % of pixels whose value lies next to a "
                          "truncation boundary -- the reference's bytes (SRCNN_MODE_REFBYTES); "
@@ -322,6 +322,8 @@ def worker(args):
         ctx.set_mode(S.MODE_SPLIT16)
     elif args.mode == "refbytes":
         ctx.set_mode(S.MODE_REFBYTES)
+    elif args.mode == "refbytes16":                                # opt-in: split-f16 kernel + exact fix-up
+        ctx.set_mode(S.MODE_REFBYTES16)
     # a real (non-null) stream that both torch's events and the HIP kernels use
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -500,7 +502,7 @@ def worker(args):
         pmc_ref = None
         pmc_stale = None
         pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists() and args.mode in ("mfma", "split16") and not stripe:
+        if pmc.exists() and args.mode in ("mfma", "split16") and not stripe:      # (the REFBYTES modes have no PMC record)
             try:
                 from srcnn_cpp_amd.build import kernel_sources_fingerprint
                 rec = json.loads(pmc.read_text())
@@ -558,8 +560,10 @@ def worker(args):
                                   "halo_transport": (("rccl send/recv" if rccl is not None else "host-staged (gloo)")
                                                      if stripe else "none (frames are independent)"),
                                   "halo_overlap": bool(stripe and not args.no_overlap)}
-        if args.mode == "refbytes":
+        if args.mode in ("refbytes", "refbytes16"):
             out["fixup"] = ctx.fixup_stats()                  # accumulated over every launch of the run
+        if args.mode == "refbytes16":
+            out["dtype"] = "f16x2-split operands, f32 accumulate + exact f32 recomputation of flagged pixels"
         if args.mode == "split16":
             # opt-in mode: priced against the dense f16 MFMA peak with the same ALGORITHMIC flops; the
             # kernel executes 42 MFMA x 32x32x16 per 32 pixels = 43,008 flop/pixel (2-3 f16 products per MAC)

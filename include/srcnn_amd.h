@@ -79,8 +79,11 @@ enum {
  *                    Output: bit-identical to the reference CPU path on every input tried; the
  *                    margin is observable (srcnn_fixup_stats).  The per-filter entry points and
  *                    the materialising path run as in MFMA mode; a pre-clamp request runs the
- *                    exact kernels. */
-enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2, SRCNN_MODE_REFBYTES = 3 };
+ *                    exact kernels.
+ *   SRCNN_MODE_REFBYTES16 opt-in, like SPLIT16 outside the float32 north star: the same flag-and-recompute
+ *                    scheme behind the split-f16 kernel (threshold 8/6 of REFBYTES': that kernel's noise is a
+ *                    little wider).  The reference's bytes at about two thirds of the float32 MFMA mode's TIME. */
+enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2, SRCNN_MODE_REFBYTES = 3, SRCNN_MODE_REFBYTES16 = 4 };
 
 typedef struct srcnn_ctx srcnn_ctx;
 

@@ -28,7 +28,7 @@ import numpy as np
 __all__ = [
     "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
-    "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "FLOP_PER_PIXEL",
+    "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "MODE_REFBYTES16", "FLOP_PER_PIXEL",
     "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
     "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
@@ -44,6 +44,7 @@ MODE_MFMA = 0
 MODE_EXACT = 1
 MODE_SPLIT16 = 2
 MODE_REFBYTES = 3          # float32 MFMA + exact fix-up of the pixels next to a truncation boundary: the reference's bytes
+MODE_REFBYTES16 = 4        # opt-in: the same behind the split-f16 kernel
 N_WEIGHTS = 8129
 # 2 x (64*81 + 32*64 + 32*25) MAC per output pixel
 FLOP_PER_PIXEL = 16064

@@ -119,6 +119,19 @@ struct FixParams {
     unsigned *scat, *dense;         // work lists: pixel y * width + x; tile index
     float delta, code_step;         // code_step = 2 delta / 253
 };
+// SRCNN_MODE_REFBYTES: the flag byte stored beside an output byte (srcnn_kernels.h, srcnn_exact.hip): 0, or 1 + the position of
+// v - rint(v) in [-delta, +delta] on a 253-step scale, for the values a rounding difference of the MFMA path could carry across
+// a truncation boundary: |v - rint(v)| <= delta and 0.5 < v < 255.5 (the store truncates toward zero and clamps: (-1, 1) -> 0,
+// >= 255 -> 255, so there is no boundary at 0 nor above 255).  The range test is ONE unsigned compare on the float's bits.
+__device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
+{
+    // (device code only; the host translation units include this header for the parameter structs)
+    const float dist = v - __builtin_rintf(v);
+    const bool live = (__builtin_fabsf(dist) <= delta) & ((__builtin_bit_cast(unsigned, v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
+    const unsigned code = (unsigned)((dist + delta) * scale + 1.5f);
+    return live ? (uint8_t)code : (uint8_t)0;
+}
+
 hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);
 size_t fixup_list_entries(int width, int rows, size_t *dense_entries);
 

@@ -205,18 +205,6 @@ __device__ __forceinline__ void relu_pairs(f32x16 &a, const f32x2 ones)
     }
 }
 
-// SRCNN_MODE_REFBYTES: the flag byte stored beside an output byte (srcnn_kernels.h, srcnn_exact.hip): 0, or 1 + the position of
-// v - rint(v) in [-delta, +delta] on a 253-step scale, for the values a rounding difference of the MFMA path could carry across
-// a truncation boundary: |v - rint(v)| <= delta and 0.5 < v < 255.5 (the store truncates toward zero and clamps: (-1, 1) -> 0,
-// >= 255 -> 255, so there is no boundary at 0 nor above 255).  The range test is ONE unsigned compare on the float's bits.
-__device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
-{
-    const float dist = v - __builtin_rintf(v);
-    const bool live = (__builtin_fabsf(dist) <= delta) & ((__float_as_uint(v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
-    const unsigned code = (unsigned)((dist + delta) * scale + 1.5f);
-    return live ? (uint8_t)code : (uint8_t)0;
-}
-
 // Kernels whose steady-state rows run through the FAST row body (see the row loop).  Convolution55 alone (MODE_L3) is
 // bound by its plane loads: the FAST body measured 0-1 % slower there (112 registers instead of 93), so it keeps the general one.
 constexpr bool fast_kernel(int mode, bool pre, int diag)

@@ -79,9 +79,13 @@ constexpr int SP_RS = 264;                      // ring row pitch in halfs: ever
 constexpr int SP_CS = 2 * YR * SP_RS + 32;
 constexpr int SP_RING_BYTES = 2 * SP_CS * 2;
 
-template <bool PRE, bool DIAG = false>
+// FIX: SRCNN_MODE_REFBYTES16 -- a flag byte beside every output byte (fix_code(), srcnn_kernels.h) for the exact fix-up kernels.
+template <bool PRE, bool DIAG = false, bool FIX = false>
 __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripParams p)
 {
+    if constexpr (FIX) {     // the launch's fix-up counters start at zero; the fix-up kernels run behind this one
+        if (blockIdx.x == 0 && threadIdx.x < FIX_COUNTERS) p.fix_counters[threadIdx.x] = 0u;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][SP_RS]
     float *fbuf = reinterpret_cast<float *>(smem + SP_RING_BYTES);        // [2][3][6][FW]
@@ -199,6 +203,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
         const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
         uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
         *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
+        if constexpr (FIX) {
+            uint8_t *f8 = ok ? p.flag + o : reinterpret_cast<uint8_t *>(p.sink) + 512 + lane;
+            *f8 = fix_code(v, p.fix_delta, p.fix_scale);
+        }
         if constexpr (PRE) {
             float *dp = ok ? p.pre + o : p.sink + 64 + lane;
             *dp = v;
@@ -502,7 +510,11 @@ hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream
     const dim3 grid((unsigned)((long)p.n_strips * p.n_segs * n_frames));
     const dim3 block(NTHREADS);
     const size_t lds = split16_lds_bytes() + lds_pad;
-    if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16_kernel<false, true>), grid, block, lds, stream, p);
+    if (p.flag) {
+        if (p.pre) return hipErrorInvalidValue;     // (the API runs pre-clamp requests of that mode on the exact kernels)
+        hipLaunchKernelGGL((srcnn_split16_kernel<false, false, true>), grid, block, lds, stream, p);
+    }
+    else if (p.tune & 2) hipLaunchKernelGGL((srcnn_split16_kernel<false, true>), grid, block, lds, stream, p);
     else if (p.pre) hipLaunchKernelGGL((srcnn_split16_kernel<true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((srcnn_split16_kernel<false>), grid, block, lds, stream, p);
     return hipGetLastError();

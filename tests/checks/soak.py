@@ -5,8 +5,8 @@ usage: python tests/checks/soak.py [seconds] [seed]
 Random plane sizes (biased to strip / unit / item-planner boundaries), padded strides, three
 content types; every result is checked: float32 MFMA mode bitwise against the FMA-order model and
 within tolerance of the reference arithmetic, split-f16 mode within tolerance, exact mode bitwise,
-REFBYTES mode (MFMA + exact fix-up of the pixels next to a truncation boundary) BYTEWISE equal to the
-reference arithmetic, with the margin its monitor reports.
+the REFBYTES modes (float32 MFMA or split-f16 kernel + exact fix-up of the pixels next to a truncation boundary) BYTEWISE equal
+to the reference arithmetic, with the margin their monitor reports.
 """
 import sys, time
 from pathlib import Path
@@ -43,9 +43,10 @@ while time.time() - t0 < budget:
         if name == "exact" and w * h > 200000: continue
         ctx.set_mode(mode)
         if name == "mfma":      # ... and the same plane in REFBYTES mode: the reference's bytes, no tolerance
-            ctx.set_mode(S.MODE_REFBYTES)
-            rb = ctx.forward_y(yv)
-            assert np.array_equal(rb, r_out), ("refbytes", w, h, kind, int((rb != r_out).sum()))
+            for rmode in (S.MODE_REFBYTES, S.MODE_REFBYTES16):
+                ctx.set_mode(rmode)
+                rb = ctx.forward_y(yv)
+                assert np.array_equal(rb, r_out), ("refbytes", rmode, w, h, kind, int((rb != r_out).sum()))
             ctx.set_mode(mode)
         pre = np.full((h, w), np.nan, np.float32)
         out = ctx.forward_y(yv, preclamp=pre)

@@ -22,6 +22,8 @@ run --steps 30 --mode refbytes                                  # the reference'
 run --steps 5 --mode refbytes --frames 64                       # ... 64 x 3840x2160
 run --steps 20 --mode refbytes --width 1920 --height 1080       # ... a 1080p plane
 run --steps 20 --mode refbytes --path pipeline                  # ... BGR 1080p -> BGR 4K
+run --steps 30 --mode refbytes16                                # opt-in: the reference's bytes behind the split-f16 kernel
+run --steps 5 --mode refbytes16 --frames 64                     # ... 64 x 3840x2160
 run --steps 50 --mode split16                                   # opt-in split-f16 mode, 1 x 3840x2160
 run --steps 5 --mode split16 --frames 64                        # opt-in split-f16 mode, 64 x 3840x2160
 run --steps 20 --mode split16 --path pipeline                   # BGR 1080p -> BGR 4K with the split-f16 conv path

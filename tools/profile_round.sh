@@ -13,6 +13,7 @@ python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2>> $OUT/bench_default.err      # the driver's exact command
 python bench.py --mode refbytes --no-cpu-baseline > $OUT/bench_refbytes.json 2>> $OUT/bench_default.err
 python bench.py --mode refbytes --frames 64 --steps 5 --no-cpu-baseline > $OUT/bench_refbytes_b64.json 2>> $OUT/bench_default.err
+python bench.py --mode refbytes16 --no-cpu-baseline > $OUT/bench_refbytes16.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --no-cpu-baseline > $OUT/bench_split16.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --frames 64 --steps 10 --no-cpu-baseline > $OUT/bench_split16_b64.json 2>> $OUT/bench_default.err
 for mode in mfma split16; do
