@@ -80,6 +80,36 @@ int main() { return 0; }
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)], check=True)
 
 
+def test_reference_call_sites_compile_with_device_planes():
+    """The text of the reference's two call sites (src/srcnn.cpp:609, :627) with ONLY the element type of the vector allocated at
+    :602-607 changed to srcnn::DevicePlane<float>: overload resolution must pick the device-plane overloads next to the generic
+    templates (a cv::Mat-shaped type for the u8 planes, as above) -- compile only."""
+    import subprocess, tempfile
+    code = r'''
+#include "srcnn_amd.hpp"
+using namespace srcnn;
+struct MatStepLike { std::size_t p[2]; operator std::size_t() const { return p[0]; } };
+struct MatLike { int flags, dims, rows, cols; unsigned char *data; MatStepLike step; };
+#define CONV2_FILTERS 32
+static float weights_conv1_data[64][9][9], biases_conv1[64], weights_conv2_data[32][64], biases_conv2[32], weights_conv3_data[32][5][5];
+static float biases_conv3;
+void driver(std::vector<MatLike> &pImg, MatLike &pImgConv3) {
+    std::vector<srcnn::DevicePlane<float>> pImgConv2 = srcnn::DevicePlanes<float>(CONV2_FILTERS, pImg[0].cols, pImg[0].rows);
+    Convolution99x11( pImg[0], pImgConv2, weights_conv1_data, biases_conv1, weights_conv2_data, biases_conv2 );
+    Convolution55( pImgConv2, pImgConv3, weights_conv3_data, biases_conv3 );
+    // ... and the host-plane form still resolves to the generic templates
+    std::vector<MatLike> host32(32);
+    Convolution99x11( pImg[0], host32, weights_conv1_data, biases_conv1, weights_conv2_data, biases_conv2 );
+    Convolution55( host32, pImgConv3, weights_conv3_data, biases_conv3 );
+}
+int main() { return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "m.cpp"
+        src.write_text(code)
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)], check=True)
+
+
 def test_create_without_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():

@@ -235,3 +235,33 @@ def test_safe_hazard_build_gives_the_same_bytes(tmp_path, weights_blob):
     assert safe == product
     m_out, _ = oracle.gpuorder_forward_y(synth_luma(300, 70), weights_blob)
     assert safe["300x70"] == zlib.crc32(m_out.tobytes())
+
+
+def test_error_paths_of_the_round3_entry_points(weights_blob):
+    w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
+    y = synth_luma(64, 32)
+    out = np.empty_like(y)
+    with S.Context(0) as ctx:
+        with pytest.raises(S.SrcnnError) as e:
+            ctx.set_mode(7)
+        assert e.value.code == S.ERR_INVALID
+        st = ctx.fixup_stats()                                  # nothing launched in a REFBYTES mode yet
+        assert st["scattered_pixels"] == 0 and st["bytes_changed"] == 0 and st["max_dev"] == 0.0
+        with pytest.raises(S.SrcnnError) as e:
+            ctx.dev_alloc(0)
+        assert e.value.code == S.ERR_INVALID
+        with pytest.raises(S.SrcnnError) as e:                  # null device planes
+            ctx.conv99x11_to_dev(y, 0, 64, 64 * 32, w1, b1, w2, b2)
+        assert e.value.code == S.ERR_INVALID
+        d = ctx.dev_alloc(32 * 64 * 32 * 4)
+        try:
+            with pytest.raises(S.SrcnnError) as e:              # plane pitch smaller than a plane
+                ctx.conv99x11_to_dev(y, d, 64, 64 * 31, w1, b1, w2, b2)
+            assert e.value.code == S.ERR_INVALID
+            ctx.conv99x11_to_dev(y, d, 64, 64 * 32, w1, b1, w2, b2)
+            ctx.conv55_from_dev(d, 64, 64 * 32, out, w3, b3)     # loads layer 3 itself: the reference passes its tables per call
+            m_out, _ = oracle.gpuorder_forward_y(y, weights_blob)
+            assert np.array_equal(out, m_out)
+        finally:
+            ctx.dev_free(d)
+        ctx.dev_free(0)                                          # freeing nothing is fine
