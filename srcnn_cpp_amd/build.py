@@ -46,10 +46,15 @@ def kernel_sources_fingerprint() -> str:
     figures bench.py quotes (profiles/pmc_traffic.json) carry the fingerprint they were taken with; a line never quotes
     counters of a different kernel build (the GPU box holds no .git, so a commit id cannot serve)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("srcnn_mfma.hip", "srcnn_split16.hip", "srcnn_kernels.h", "srcnn_api.cpp"):
-        h.update((CSRC / name).read_bytes())
-    return h.hexdigest()[:16]
+        text = (CSRC / name).read_text()
+        # the CODE, not its commentary: comments removed (no string literal of these files holds "//" or "/*"), white space collapsed
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode())
+    return "c2-" + h.hexdigest()[:16]
 
 
 def hipcc() -> str:

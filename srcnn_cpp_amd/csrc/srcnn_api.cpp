@@ -1020,7 +1020,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
     const int halo = (mode == MODE_L12) ? 0 : 2;
     // Undocumented experiment knobs (never set in production).  Only bits that leave every output byte as it is are honoured:
     // 2 / 16 = the stamped builds of the split-f16 / float32 production kernel (tools/diag_split16.py, diag_light.py), 8 = no XCD remap,
-    // 128 = small batches on the regular grid.  A stray SRCNN_DEBUG_TUNE cannot change a pixel (tests/test_gpu_parity.py).
+    // 128 = small batches on the regular grid.  A stray SRCNN_DEBUG_TUNE cannot change a pixel (tests/test_gpu_hardening.py).
     static const char *env_tune = std::getenv("SRCNN_DEBUG_TUNE");
     static const char *env_pad = std::getenv("SRCNN_DEBUG_LDS_PAD");
     constexpr int kTuneHarmless = 2 | 8 | 16 | 128;
