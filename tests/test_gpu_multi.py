@@ -195,3 +195,25 @@ def test_bench_line_reports_both_clock_regimes_and_e2e():
     assert d["e2e"]["value"] > 0 and d["e2e"]["output_equals_resident"] is True and d["e2e"]["value"] < d["value"]
     assert "closing_barrier_ms" in d["timing"]
     assert d["roofline"]["traffic"] is None or d["pmc_reference"]["traffic"] == d["roofline"]["traffic"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- every process is a rank (RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment), rank 0 prints the ONE line as the last line of its stdout.  Two ranks sharing cuda:0 here."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--shared-gpu", "--no-cpu-baseline", "--width", "1920", "--height", "1080"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["timing"]["closing_barrier_ms"] >= 0 and d["cold_start"]["ms_per_step"] > 0
+    one = run_bench("--gpus", 1, "--frames", 2, "--width", 1920, "--height", 1080)
+    assert d["config"]["output_crc32"] == one["config"]["output_crc32"]
