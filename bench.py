@@ -403,6 +403,13 @@ def worker(args):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        if dist is not None:
+            # ... and a common start: ranks leave a gloo barrier 50-200 us apart, 0.5-1 % of the driver's 20-step window.  The
+            # ranks of a node share one monotonic clock, so rank 0 names an instant 2 ms ahead and everybody spins up to it.
+            go = torch.tensor([time.perf_counter() + 0.002], dtype=torch.float64)
+            dist.broadcast(go, src=0)
+            while time.perf_counter() < float(go.item()):
+                pass
         t_a = time.perf_counter()
         ev_a.record(stream)
         for _ in range(k_steps):
