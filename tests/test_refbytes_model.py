@@ -1,0 +1,52 @@
+"""CPU check of the PRINCIPLE behind SRCNN_MODE_REFBYTES (csrc/srcnn_exact.hip), with the two CPU
+restatements only -- oracle/srcnn_gpuorder.c is bitwise the GPU's float32 MFMA path, oracle/srcnn_oracle.c the reference
+arithmetic: a byte of the MFMA path can differ from the reference's only where its pre-truncation value v lies within delta of
+an integer (and 0.5 < v < 255.5), so replacing exactly those pixels by the reference's gives the reference's plane.  The GPU
+tests (tests/test_gpu_refbytes.py) check the kernels; this checks the selection rule and the threshold the library derives
+from the model, on the CPU suite's budget."""
+import numpy as np
+import pytest
+
+import oracle
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_luma
+
+
+def shipped_delta(blob):
+    """fixup_delta() of srcnn_api.cpp: 6 * 2^-24 * ||W3||_2 * (rigorous bound of the layer-2 map for any 8-bit input)."""
+    w1, b1, w2, b2, w3, _ = S.split_weights(blob)
+    w1, w2, w3 = np.asarray(w1, np.float64).reshape(64, 81), np.asarray(w2, np.float64).reshape(32, 64), np.asarray(w3, np.float64)
+    a1 = np.maximum(0.0, 255.0 * np.maximum(w1, 0).sum(1) + np.asarray(b1, np.float64))
+    m2 = (np.maximum(w2, 0) @ a1 + np.asarray(b2, np.float64)).max()
+    return 6.0 * 2.0 ** -24 * np.sqrt((w3 ** 2).sum()) * m2
+
+
+def planes():
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:150, 0:260]
+    yield "synthetic", synth_luma(260, 150, frame=4)
+    yield "white noise", rng.integers(0, 256, (150, 260), dtype=np.uint8)
+    yield "bright ramp", np.clip(200 + xx * 55 // 260 + rng.integers(0, 4, (150, 260)), 0, 255).astype(np.uint8)
+    yield "checkerboard", np.where(((yy // 8) + (xx // 8)) % 2 == 0, 16, 240).astype(np.uint8)
+    yield "constant", np.full((60, 90), 128, np.uint8)
+    yield "tiny", synth_luma(5, 3, frame=1)
+
+
+def test_threshold_of_the_shipped_model(weights_blob):
+    assert abs(shipped_delta(weights_blob) - 1.972e-3) < 2e-6          # what srcnn_fixup_stats reports on the GPU
+
+
+@pytest.mark.parametrize("name,y", list(planes()), ids=[n for n, _ in planes()])
+def test_flagged_pixels_are_all_that_can_differ(weights_blob, name, y):
+    delta = shipped_delta(weights_blob)
+    g_out, g_pre = oracle.gpuorder_forward_y(y, weights_blob)          # the MFMA path, bit for bit
+    r_out, r_pre = oracle.forward_y(y, weights_blob)                   # the reference arithmetic
+    flagged = (np.abs(g_pre - np.rint(g_pre)) <= delta) & (g_pre > 0.5) & (g_pre < 255.5)
+    fixed = np.where(flagged, r_out, g_out)                            # recompute exactly the flagged pixels
+    assert np.array_equal(fixed, r_out), f"{name}: {(fixed != r_out).sum()} bytes differ outside the flagged set"
+    # the margin: the noise stays far below the threshold, and the threshold stays selective on textured content
+    live = (g_pre > 0.5) & (g_pre < 255.5)
+    if live.any():
+        assert np.abs(g_pre - r_pre)[live].max() < 0.5 * delta
+    if name in ("synthetic", "white noise", "bright ramp"):
+        assert flagged.mean() < 0.012
