@@ -429,10 +429,13 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                 const unsigned pix = p.scat[first + tid];
                 const long o = (long)((int)(pix / (unsigned)W) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
                 // how far the MFMA path's value was from the reference's: v_mfma = rint(v) + (code's distance), rint(v) = the
-                // stored byte (+ 1 where v sat just below the integer)
+                // stored byte (+ 1 where v sat just below the integer).  The code resolves the distance to delta / 253, so a v
+                // AT an integer can decode to the other side of it: the difference is therefore taken modulo 1 (both
+                // values lie within delta << 0.5 of the same integer)
                 const float dist = ((float)p.flag[o] - 1.f) * p.code_step - p.delta;
                 const float v_mfma = (float)p.dst[o] + (dist < 0.f ? 1.f : 0.f) + dist;
-                atomicMax(&s_maxdev, __float_as_uint(fabsf(v_mfma - temp)));
+                const float dev = v_mfma - temp;
+                atomicMax(&s_maxdev, __float_as_uint(fabsf(dev - rintf(dev))));
                 if (p.dst[o] != q) { p.dst[o] = q; atomicAdd(&s_changed, 1u); }
             }
         }
