@@ -424,7 +424,7 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     const float *w3 = k55 ? k55 : zero_w.data();
     std::vector<float> frag((size_t)NFRAG * 64);
     pack_fragments(w1, b1, w2, b2, w3, frag.data());
-    std::vector<float> raw(8129 + 2048);     // + W2 transposed [64][32] for the exact layer-1/2 kernel
+    std::vector<float> raw(8129 + 2048 + 5184);     // + W2 transposed [64][32] for the exact layer-1/2 kernel, + W1 transposed [81][64] (fix-up)
     std::memcpy(raw.data(), b1, 64 * 4);
     std::memcpy(raw.data() + 64, w1, 5184 * 4);
     std::memcpy(raw.data() + 5248, b2, 32 * 4);
@@ -433,6 +433,8 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     std::memcpy(raw.data() + 7329, w3, 800 * 4);
     for (int k = 0; k < 32; ++k)
         for (int i = 0; i < 64; ++i) raw[8129 + i * 32 + k] = w2[k * 64 + i];
+    for (int ch = 0; ch < 64; ++ch)
+        for (int t = 0; t < 81; ++t) raw[10177 + t * 64 + ch] = w1[ch * 81 + t];
     std::vector<uint8_t> frag16(S16_TABLE_BYTES);
     pack_fragments16(w1, b1, w2, b2, w3, frag16.data());
     int rc;

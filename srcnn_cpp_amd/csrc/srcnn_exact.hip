@@ -72,23 +72,94 @@ __global__ __launch_bounds__(256) void conv11_exact_kernel(const float *__restri
 }
 
 // ---- Convolution99x11, exact ---------------------------------------------
-// One pixel per lane, everything in registers: the 81 window pixels, and the 32
-// layer-2 accumulators.  Layer 2 sums its inputs in ascending channel order
-// (src/srcnn.cpp:312-315), so each layer-1 activation t_i is folded into the 32
-// running sums as soon as it exists -- same order, same roundings, no 64-float
-// scratch per pixel.  Weights are wave-uniform and come through the scalar
-// cache: weights = b1[64] | W1[64][81] | b2[32] | W2[32][64] (convdata.h order),
-// w2t = W2 transposed to [64][32] so that one channel's 32 weights are contiguous.
-// Layers 1 and 2 of ONE feature position, reference order (src/srcnn.cpp:288-321): px = its 9x9 window as floats,
-// r = the 32 layer-2 activations (bias and ReLU applied).  Shared by the whole-plane kernel below and by the fix-up
-// kernel of SRCNN_MODE_REFBYTES.
+// One feature position per lane.  The 64 layer-1 sums of the position live in registers and advance tap by tap; layer 2
+// then sums its inputs in ascending channel order (src/srcnn.cpp:312-315) -- same products, same order, same roundings as
+// the reference.  Weights are wave-uniform and come through the scalar cache: weights = b1[64] | W1[64][81] | b2[32] |
+// W2[32][64] | b3 | W3 (convdata.h order, 8,129 floats), then W2 transposed to [64][32] and W1 transposed to [81][64], so that
+// what one step of either loop needs is contiguous.  exact_layers12_lds() is shared by the whole-plane kernel below and by
+// the fix-up kernel of SRCNN_MODE_REFBYTES.
 // The weight tables are read through the CONSTANT address space: wave-uniform addresses there become scalar loads (s_load,
 // through the scalar cache, no vector-memory latency in the channel loop) whatever else the kernel stores to global memory --
 // for a plain global pointer the compiler keeps scalar loads only while it can prove no store of the kernel may alias them,
 // which the fix-up kernel's byte stores defeat: 16 vector loads per channel, each waited for at once, 3 x the time.
 typedef const __attribute__((address_space(4))) float *cfloat_p;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cfloat_p as_constant(const float *p) { return (cfloat_p)p; }
 
+// Layers 1-2 of ONE feature position per lane, the luma window read from LDS: ywin[row_of(i) + cofs[j]] is the (already
+// border-replicated) value under tap (i, j).  Tap-outer: the 64 layer-1 sums of the position advance together, one luma value
+// against the 64 weights of its tap (W1 transposed [81][64] at wraw + 10177) -- per channel the same rounded products added in
+// the same order as the reference's loop (src/srcnn.cpp:283-305), but 64 independent chains instead of one dependent chain per
+// channel, two channels per packed instruction (v_pk_mul_f32 / v_pk_add_f32 with the weights as an SGPR pair:
+// profiles/r03/pk_f32_probe.txt), and no 81-register window.  The 64 weights of a tap are fetched as four 16-float scalar
+// loads issued TOGETHER: scalar loads return out of order, so every wait is lgkmcnt(0), and left to itself the compiler issues
+// one load right before its use -- the wave then stalls for the scalar cache's latency 452 times per position (fix_apply_kernel
+// 334 us per 3840x2160 plane in that form, 250 in this one; a half-tap software pipeline on top: no further gain; the
+// same grouping in layer 2: 3 % slower).  Layer 2: r[k] = r[k] + a_i * W2[k][i], i ascending (:307-317), 32 independent chains.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) f32x16 *cvec16_p;
+
+template <class RowOf>
+__device__ __forceinline__ void exact_layers12_lds(const float *ywin, RowOf row_of, const int (&cofs)[9], const float *wraw,
+                                                   float (&r)[32])
+{
+    const cfloat_p wr = as_constant(wraw);
+    const cfloat_p b1 = wr, b2 = wr + 5248, w2t = wr + 8129, w1t = wr + 10177;
+    f32x2 acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = f32x2{0.f, 0.f};
+#pragma unroll 1
+    for (int i = 0; i < 9; ++i) {
+        const int ro = row_of(i);
+        const cvec16_p wrow = (cvec16_p)(w1t + i * 9 * 64);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float yv = ywin[ro + cofs[j]];
+            const f32x2 yy = {yv, yv};
+            const f32x16 w0 = wrow[4 * j], w1 = wrow[4 * j + 1], w2 = wrow[4 * j + 2], w3 = wrow[4 * j + 3];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x2 a0 = {w0[2 * c], w0[2 * c + 1]}, a1 = {w1[2 * c], w1[2 * c + 1]};
+                const f32x2 a2 = {w2[2 * c], w2[2 * c + 1]}, a3 = {w3[2 * c], w3[2 * c + 1]};
+                const f32x2 p0 = a0 * yy, p1 = a1 * yy, p2 = a2 * yy, p3 = a3 * yy;
+                acc[c] = acc[c] + p0;
+                acc[8 + c] = acc[8 + c] + p1;
+                acc[16 + c] = acc[16 + c] + p2;
+                acc[24 + c] = acc[24 + c] + p3;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const f32x2 bv = {b1[2 * c], b1[2 * c + 1]};
+        f32x2 a = acc[c] + bv;
+        a.x = (a.x < 0) ? 0.f : a.x;
+        a.y = (a.y < 0) ? 0.f : a.y;
+        acc[c] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const float ai = (i & 1) ? acc[i >> 1].y : acc[i >> 1].x;
+        const cfloat_p w2i = w2t + i * 32;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float pr = ai * w2i[k];
+            r[k] = r[k] + pr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const float v = r[k] + b2[k];
+        r[k] = (v < 0) ? 0.f : v;
+    }
+}
+
+// The whole-plane kernel keeps the register form: the 81 window values of the lane's pixel in registers, one layer-1 channel
+// after the other, each activation folded into the 32 layer-2 sums as soon as it exists.  (Measured on one box, 3840x2160:
+// this form 1.90 ms, the tap-outer form above from an LDS tile 2.13 ms packed / 2.06 ms unpacked -- the opposite order of
+// the fix-up kernel's 328 / 252 / 277 us, whose lanes gather scattered windows and share the CU with fewer waves.)
 __device__ __forceinline__ void exact_layers12(const float (&px)[81], const float *weights_, const float *w2t_, float (&r)[32])
 {
     const cfloat_p weights = as_constant(weights_), w2t = as_constant(w2t_);
@@ -314,7 +385,6 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     const unsigned n_items = n_dense + (n_scat + FIX_GROUP - 1) / FIX_GROUP;
     const int W = p.width, H = p.height;
     const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE;
-    const float *w2t = p.wraw + 8129;
     const float b3 = p.wraw[7328];
     for (;;) {
         __syncthreads();                         // s_item's readers of the previous round are done (and the kernel's LDS set-up)
@@ -369,19 +439,14 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         }
         __syncthreads();
         // ---- layers 1-2 of this lane's position ----
-        float win[81];
-        int cofs[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) cofs[j] = wbase + clampi_e(px_ + j - 4, 0, W - 1) - wx0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int ro = (clampi_e(py + i - 4, 0, H - 1) - wy0) * wpitch;
-#pragma unroll
-            for (int j = 0; j < 9; ++j) win[i * 9 + j] = ywin[ro + cofs[j]];
-        }
         float r[32];
-        exact_layers12(win, p.wraw, w2t, r);
-        __syncthreads();                          // the previous item's readers are done with Fs
+        {
+            int cofs[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) cofs[j] = wbase + clampi_e(px_ + j - 4, 0, W - 1) - wx0;
+            exact_layers12_lds(ywin, [&](int i) { return (clampi_e(py + i - 4, 0, H - 1) - wy0) * wpitch; }, cofs, p.wraw, r);
+        }
+        __syncthreads();                          // every lane is done with the luma window, the previous item's readers with Fs (same LDS)
 #pragma unroll
         for (int k = 0; k < 32; ++k) Fs[tid][k] = r[k];
         __syncthreads();
@@ -493,7 +558,7 @@ hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_fra
                                   long stride, long pitch, long frame_pitch, int w, int h, int n_frames,
                                   const float *d_weights, hipStream_t st)
 {
-    // d_weights = convdata.h-order table (8,129 floats) followed by W2 transposed ([64][32])
+    // d_weights = convdata.h-order table (8,129 floats) followed by W2 transposed ([64][32]) and W1 transposed ([81][64])
     hipLaunchKernelGGL(conv99x11_exact_kernel, px_grid(w, h, n_frames), dim3(256), 0, st, src, sstride,
                        src_frame_pitch, planes, stride, pitch, frame_pitch, w, h, d_weights, d_weights + 8129);
     return hipGetLastError();

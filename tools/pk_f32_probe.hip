@@ -9,10 +9,11 @@
 #include <vector>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { PLAIN_MULADD = 0, PLAIN_MULADD_S, PK_MULADD, PK_MULADD_S, PLAIN_FMA, PK_FMA, PK_MULADD_BCAST_S, N_VARIANTS };
+enum { PLAIN_MULADD = 0, PLAIN_MULADD_S, PK_MULADD, PK_MULADD_S, PLAIN_FMA, PK_FMA, PK_MULADD_BCAST_S, PLAIN_CHAIN_S, N_VARIANTS };
 static const char *kNames[N_VARIANTS] = {"v_mul_f32 + v_add_f32 (vgpr weights)", "v_mul_f32 + v_add_f32 (sgpr weights)",
                                          "v_pk_mul_f32 + v_pk_add_f32 (vgpr weights)", "v_pk_mul_f32 + v_pk_add_f32 (sgpr pair)",
-                                         "v_fma_f32", "v_pk_fma_f32", "v_pk_mul (op_sel broadcast x, sgpr pair) + v_pk_add"};
+                                         "v_fma_f32", "v_pk_fma_f32", "v_pk_mul (op_sel broadcast x, sgpr pair) + v_pk_add",
+                                         "v_mul_f32 + v_add_f32, ONE dependent add chain (sgpr weights)"};
 
 template <int V>
 __global__ __launch_bounds__(256) void probe(const float *__restrict__ in, float *__restrict__ out, int iters)
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ in, float
                 asm volatile("v_mul_f32 %0, %2, %1" : "=v"(p1) : "v"(x), "s"(wsp.y));
                 asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[q]) : "v"(p0));
                 asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc[q + 1]) : "v"(p1));
+            } else if constexpr (V == PLAIN_CHAIN_S) {        // what exact_layers12's tap loop is: a = a + w[q] * px[q]
+                float p0, p1;
+                asm volatile("v_mul_f32 %0, %2, %1" : "=v"(p0) : "v"(acc[q]), "s"(wsp.x));
+                asm volatile("v_mul_f32 %0, %2, %1" : "=v"(p1) : "v"(acc[q + 1]), "s"(wsp.y));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(p0));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(p1));
             } else if constexpr (V == PK_MULADD) {
                 f32x2 p, a = {acc[q], acc[q + 1]};
                 asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(p) : "v"(xx), "v"(wvp));
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ in, float
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += acc[q];
-    out[t] = s;
+    out[t] = s + x;
 }
 
 template <int V>
@@ -109,12 +116,12 @@ int main()
     const int iters = 20000;
     // float32 operations (a multiply or an add; an FMA counts two) per lane per iteration: 32 in every variant
     printf("%d CUs; %d iterations x 32 float32 operations per lane; ms per launch (best of 5), cycles per lane-operation at 2.4 GHz\n", n_cu, iters);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 2, 4, 5, 6, 8}) {
         float ms[N_VARIANTS];
         ms[0] = run<0>(d_in, d_out, n_cu, w, iters); ms[1] = run<1>(d_in, d_out, n_cu, w, iters);
         ms[2] = run<2>(d_in, d_out, n_cu, w, iters); ms[3] = run<3>(d_in, d_out, n_cu, w, iters);
         ms[4] = run<4>(d_in, d_out, n_cu, w, iters); ms[5] = run<5>(d_in, d_out, n_cu, w, iters);
-        ms[6] = run<6>(d_in, d_out, n_cu, w, iters);
+        ms[6] = run<6>(d_in, d_out, n_cu, w, iters); ms[7] = run<7>(d_in, d_out, n_cu, w, iters);
         for (int v = 0; v < N_VARIANTS; ++v)
             printf("  %d wave(s)/SIMD  %-58s %8.3f ms  %6.2f wave-cycles per wave-op (64 lanes)  x%.2f of plain\n", w, kNames[v], ms[v],
                    ms[v] * 1e-3 * 2.4e9 / ((double)iters * 32.0 * w), ms[v] / ms[0]);
