@@ -570,7 +570,15 @@ def worker(args):
         if args.mode in ("refbytes", "refbytes16"):
             out["fixup"] = ctx.fixup_stats()                  # accumulated over every launch of the run
         if args.mode == "refbytes16":
+            # opt-in mode: the split-f16 kernel is priced against the dense f16 MFMA peak (as --mode split16 below); the
+            # fix-up is vector-ALU work, so the line's frac is only the ALGORITHMIC rate of the whole step over that peak
             out["dtype"] = "f16x2-split operands, f32 accumulate + exact f32 recomputation of flagged pixels"
+            out["roofline"].update({"peak": PEAK_F16_MFMA_TFLOPS, "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+                                    "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                                    "note": "strip kernel on f16 MFMAs + fix_collect / fix_apply on the vector ALU in one figure"})
+        if args.mode == "refbytes":
+            out["roofline"]["note"] = ("the step is the f32-MFMA strip kernel (its own frac: --mode mfma) plus fix_collect / fix_apply "
+                                       "on the vector ALU; frac here is the algorithmic rate of the whole step over the f32-MFMA peak")
         if args.mode == "split16":
             # opt-in mode: priced against the dense f16 MFMA peak with the same ALGORITHMIC flops; the
             # kernel executes 42 MFMA x 32x32x16 per 32 pixels = 43,008 flop/pixel (2-3 f16 products per MAC)

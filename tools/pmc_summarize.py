@@ -9,7 +9,8 @@ HALF the bytes of a streaming read whatever its width (byte, dword and dwordx4 l
 tools/pmc_calib.hip: profiles/r02/pmc_calibration.txt), WRITE_SIZE is exact within 2 %, so
 reads = FETCH_SIZE * 1024 * 2, writes = WRITE_SIZE * 1024 for every kernel.
 """
-import csv, glob, json, os, sys
+import csv
+import re, glob, json, os, sys
 from collections import defaultdict
 
 out = sys.argv[1]
@@ -17,6 +18,15 @@ out = sys.argv[1]
 # two launches, srcnn_seam_kernel + srcnn_cseam_kernel, for plans whose seam windows are not kept apart) finishes the rows /
 # columns at item and strip boundaries -- their HBM bytes belong to the step's traffic
 KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seams_merged_kernel", "srcnn_seam_kernel", "srcnn_cseam_kernel"], "split16": ["srcnn_split16_kernel"]}
+
+
+def writes_flags(name):
+    """The SRCNN_MODE_REFBYTES instantiations (last template argument FIX = true) also run in a default bench -- its `refbytes`
+    leg -- and store a flag plane besides: they are not the kernels of the float32 headline step."""
+    m = re.search(r"<([^<>]*)>\(", name)
+    return bool(m) and m.group(1).split(",")[-1].strip() == "true"
+
+
 traffic_rec = {}
 for mode, knames in KERNEL.items():
     kname = knames[0]
@@ -27,6 +37,8 @@ for mode, knames in KERNEL.items():
     for f in glob.glob(os.path.join(out, f"pmc_{mode}_*", "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
+                if writes_flags(row["Kernel_Name"]):
+                    continue
                 if kname in row["Kernel_Name"]:
                     sums[row["Counter_Name"]] += float(row["Counter_Value"])
                     cnt[row["Counter_Name"]] += 1
@@ -65,7 +77,7 @@ for mode, knames in KERNEL.items():
             rows = list(csv.reader(fh))
         stats_rows = rows
         for r in rows[1:]:
-            if kname in r[0]:
+            if kname in r[0] and not writes_flags(r[0]):
                 avg_ns = float(r[3])
     if stats_rows:
         with open(os.path.join(out, f"{mode}_4k_kernel_stats.csv"), "w", newline="") as fh:

@@ -47,10 +47,12 @@ python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
 tools/stripe_overhead.sh $OUT/stripe_overhead.txt > /dev/null 2>&1
 python tests/checks/soak.py 120 31 > $OUT/soak.txt 2>&1
 python tests/checks/soak_paths.py 60 37 > $OUT/soak_paths.txt 2>&1
+python tests/checks/soak_models.py 240 3 > $OUT/soak_models.txt 2>&1
 python tests/checks/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
 python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
 [ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
 [ -x build/mfma_probe ] && ./build/mfma_probe > $OUT/mfma_probe.txt 2>&1
+[ -x build/pk_f32_probe ] && ./build/pk_f32_probe > $OUT/pk_f32_probe.txt 2>&1
 # keep the merge small: the raw per-dispatch csv files are summarised on the box
 python tools/pmc_summarize.py $OUT > $OUT/pmc_summarize.log 2>&1
 find $OUT -name "*counter_collection.csv" -size +2M -delete
