@@ -1021,7 +1021,9 @@ int frames_per_launch(const srcnn_ctx *c, int width, int height, int n_frames)
 }
 
 // Common launch of the three strip modes on device memory.
-int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
+// fix_frame / fix_frames (SRCNN_MODE_REFBYTES only): this single-frame launch is frame `fix_frame` of a batch of `fix_frames`
+// whose flagged pixels ONE fix-up finishes, queued behind the batch's last launch (fix_frames = 1: the launch's own fix-up).
+int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame = 0, int fix_frames = 1)
 {
     const int halo = (mode == MODE_L12) ? 0 : 2;
     // Undocumented experiment knobs (never set in production).  Only bits that leave every output byte as it is are honoured:
@@ -1170,18 +1172,25 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         }
     }
     // SRCNN_MODE_REFBYTES: the fused float32 kernel also writes a flag byte per pixel; fix_collect / fix_apply then recompute
-    // the flagged pixels in the reference's arithmetic (srcnn_exact.hip).  One frame per launch (srcnn_forward_y_dev).
+    // the flagged pixels in the reference's arithmetic (srcnn_exact.hip).  One frame per strip launch; the fix-up of up to
+    // FIX_BATCH_FRAMES consecutive frames of a batch is ONE pair of launches behind the last of them (srcnn_forward_y_dev): its
+    // items are drawn from one list, so the draw's tail -- 3.3 rounds of items on a single 3840x2160 plane leave 18 % of the wave
+    // slots empty -- is paid once per batch.
     const bool fix = mode == MODE_FUSED && (c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16) && !p.pre;
     srcnn_ctx::SeamScratch *fsc = nullptr;
-    size_t fix_scat_cap = 0, fix_dense_cap = 0;
+    size_t fix_scat_cap = 0, fix_dense_cap = 0, fix_flag_pitch = 0;
     float fix_delta_used = 0.f;
     if (fix) {
-        if (n_frames != 1) return fail(c, SRCNN_ERR_STATE, "REFBYTES launches hold one frame");
+        if (n_frames != 1 || fix_frame < 0 || fix_frame >= fix_frames || fix_frames > FIX_BATCH_FRAMES)
+            return fail(c, SRCNN_ERR_STATE, "REFBYTES strip launches hold one frame");
         int rc;
         if ((rc = seam_scratch_for_stream(c, &fsc))) return rc;
         const int rows = p.row_end - p.row_begin;
-        fix_scat_cap = fixup_list_entries(p.width, rows, &fix_dense_cap);
-        if ((rc = reserve(c, fsc->flag, (size_t)rows * (size_t)p.dst_stride))) return rc;
+        fix_scat_cap = fixup_list_entries(p.width, rows, &fix_dense_cap) * (size_t)fix_frames;
+        fix_dense_cap *= (size_t)fix_frames;
+        fix_flag_pitch = (size_t)rows * (size_t)p.dst_stride;
+        // (sized for the whole batch at its first frame: no buffer moves while earlier frames' flags wait for the fix-up)
+        if ((rc = reserve(c, fsc->flag, fix_flag_pitch * (size_t)fix_frames))) return rc;
         if ((rc = reserve(c, fsc->fix_lists, (fix_scat_cap + fix_dense_cap) * sizeof(unsigned)))) return rc;
         if ((rc = reserve(c, fsc->fix_counters, FIX_COUNTERS * sizeof(unsigned)))) return rc;
         if (!c->fix_totals.p) {
@@ -1189,7 +1198,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
             HIP_TRY(c, hipMemsetAsync(c->fix_totals.p, 0, FIX_COUNTERS * sizeof(unsigned), c->stream));
         }
         // flag[o] for the same element offsets o as dst: o >= (row_begin - dst_row0) * dst_stride
-        p.flag = static_cast<uint8_t *>(fsc->flag.p) - (long)(p.row_begin - p.dst_row0) * p.dst_stride;
+        p.flag = static_cast<uint8_t *>(fsc->flag.p) + (size_t)fix_frame * fix_flag_pitch - (long)(p.row_begin - p.dst_row0) * p.dst_stride;
         // (the split-f16 kernel's noise is a little wider than the float32 kernel's -- soak: 4.3e-4 against 3.7e-4 -- and has no
         // CPU model to take statistics from: 8 * E0 instead of 6 * E0, and the same monitor)
         fix_delta_used = c->mode == SRCNN_MODE_REFBYTES16 ? c->fix_delta * (8.f / 6.f) : c->fix_delta;
@@ -1219,13 +1228,17 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames)
         if (p.seam) HIP_TRY(c, launch_seams(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p), c->stream));
         if (p.cseam) HIP_TRY(c, launch_cseams(p, n_frames, c->stream));
     }
-    if (fix) {
+    if (fix && fix_frame == fix_frames - 1) {
         FixParams f{};
-        f.src = p.src;
+        f.n_frames = fix_frames;                         // frame 0 of the batch lies fix_frame frames before this launch's
+        f.src_frame_pitch = p.src_frame_pitch;
+        f.dst_frame_pitch = p.dst_frame_pitch;
+        f.flag_frame_pitch = (long)fix_flag_pitch;
+        f.src = p.src - (long)fix_frame * p.src_frame_pitch;
         f.src_stride = p.src_stride;
         f.src_row0 = p.src_row0;
-        f.dst = p.dst;
-        f.flag = p.flag;
+        f.dst = p.dst - (long)fix_frame * p.dst_frame_pitch;
+        f.flag = p.flag - (long)fix_frame * (long)fix_flag_pitch;
         f.dst_stride = p.dst_stride;
         f.dst_row0 = p.dst_row0;
         f.width = p.width;
@@ -1800,7 +1813,11 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         p.height = height;
         p.row_begin = 0;
         p.row_end = height;
-        if ((rc = run_strip(c, MODE_FUSED, p, std::min(kMaxFrames, n_frames - f0)))) return rc;
+        const bool refbytes = c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16;      // (kMaxFrames is 1)
+        const int batch0 = f0 - f0 % FIX_BATCH_FRAMES;
+        if ((rc = run_strip(c, MODE_FUSED, p, std::min(kMaxFrames, n_frames - f0), refbytes ? f0 - batch0 : 0,
+                            refbytes ? std::min(FIX_BATCH_FRAMES, n_frames - batch0) : 1)))
+            return rc;
     }
     return SRCNN_OK;
 }

@@ -321,11 +321,13 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
     __syncthreads();
     const int tiles_x = (p.width + FIX_TILE - 1) / FIX_TILE;
     const int segs = (tiles_x + FIX_SEG_TILES - 1) / FIX_SEG_TILES;
-    const int band = blockIdx.x / segs, seg = blockIdx.x - band * segs;
+    const int bands = (p.row_end - p.row_begin + FIX_TILE - 1) / FIX_TILE;
+    const int frame = blockIdx.x / (bands * segs), bs = blockIdx.x - frame * (bands * segs);
+    const int band = bs / segs, seg = bs - band * segs;
     const int y0 = p.row_begin + band * FIX_TILE, nr = min(FIX_TILE, p.row_end - y0);
     const int x = seg * FIX_SEG_COLS + 4 * tid;                  // this thread's 4 columns
     const int tile = tid / 3;                                    // within the segment
-    const uint8_t *f0 = p.flag + (long)(y0 - p.dst_row0) * p.dst_stride + x;
+    const uint8_t *f0 = p.flag + (long)frame * p.flag_frame_pitch + (long)(y0 - p.dst_row0) * p.dst_stride + x;
     const bool aligned = ((p.dst_stride | (long)(size_t)p.flag) & 3) == 0;      // uniform
     unsigned rows_dw[FIX_TILE];
     unsigned cnt = 0;
@@ -348,14 +350,14 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
     }
     __syncthreads();
     if (tid < FIX_SEG_TILES && s_cnt[tid] >= FIX_DENSE_MIN)
-        s_dense[atomicAdd(&s_ndense, 1u)] = (unsigned)(band * tiles_x + seg * FIX_SEG_TILES + tid);
+        s_dense[atomicAdd(&s_ndense, 1u)] = (unsigned)((frame * bands + band) * tiles_x + seg * FIX_SEG_TILES + tid);
     if (cnt && s_cnt[tile] < FIX_DENSE_MIN) {
         unsigned at = atomicAdd(&s_nscat, cnt);
 #pragma unroll
         for (int r = 0; r < FIX_TILE; ++r) {
             unsigned dw = rows_dw[r];
             for (int b = 0; dw; ++b, dw >>= 8)
-                if (dw & 0xffu) s_scat[at++] = (unsigned)(y0 + r) * (unsigned)p.width + (unsigned)(x + b);
+                if (dw & 0xffu) s_scat[at++] = (unsigned)(frame * p.height + y0 + r) * (unsigned)p.width + (unsigned)(x + b);
         }
     }
     __syncthreads();
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     const unsigned n_dense = p.counters[FIX_N_DENSE], n_scat = p.counters[FIX_N_SCAT];
     const unsigned n_items = n_dense + (n_scat + FIX_GROUP - 1) / FIX_GROUP;
     const int W = p.width, H = p.height;
-    const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE;
+    const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE, bands = (p.row_end - p.row_begin + FIX_TILE - 1) / FIX_TILE;
     const float b3 = p.wraw[7328];
     for (;;) {
         __syncthreads();                         // s_item's readers of the previous round are done (and the kernel's LDS set-up)
@@ -403,20 +405,23 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         int py, px_;                             // this lane's feature position (clamped image coordinates)
         int wy0, wx0, wbase, wpitch;             // origin (image coordinates), LDS base and pitch of the window this lane reads
         bool active;
-        int ty0 = 0, tx0 = 0;
+        int ty0 = 0, tx0 = 0, frame = 0;
         unsigned first = 0;
         // (rows beyond row_end + 5 feed no pixel of this launch: a row stripe's caller provides [row_begin - 6, row_end + 6))
         const int y_hi = min(H - 1, p.row_end + 5);
         if (dense) {
             const unsigned t = p.dense[item];
-            ty0 = p.row_begin + (int)(t / (unsigned)tiles_x) * FIX_TILE;
+            const unsigned trow = t / (unsigned)tiles_x;                 // frame * bands + band
+            frame = (int)(trow / (unsigned)bands);
+            ty0 = p.row_begin + (int)(trow % (unsigned)bands) * FIX_TILE;
             tx0 = (int)(t % (unsigned)tiles_x) * FIX_TILE;
             py = clampi_e(ty0 - 2 + tid / FIX_POS, 0, min(H - 1, p.row_end + 1));     // (positions below row_end + 1 feed no pixel)
             px_ = clampi_e(tx0 - 2 + tid % FIX_POS, 0, W - 1);
             wy0 = ty0 - 6; wx0 = tx0 - 6; wbase = 0; wpitch = FIX_POS + 8;
             for (int e = tid; e < (FIX_POS + 8) * (FIX_POS + 8); e += 256) {
                 const int yy = wy0 + e / (FIX_POS + 8), xx = wx0 + e % (FIX_POS + 8);
-                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W) ywin[e] = (float)p.src[(long)(yy - p.src_row0) * p.src_stride + xx];
+                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
+                    ywin[e] = (float)p.src[(long)frame * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
             }
         } else {
             first = (item - n_dense) * FIX_GROUP;
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
             // (idle lanes recompute the group's first pixel: any other coordinates could lie outside a row stripe's input)
             const unsigned oo = active ? o : 0u;
             const unsigned pix = p.scat[first + oo];
-            const int y = (int)(pix / (unsigned)W), x = (int)(pix % (unsigned)W);
+            const int y = (int)((pix / (unsigned)W) % (unsigned)H), x = (int)(pix % (unsigned)W);
             py = clampi_e(y + (int)(tap / 5u) - 2, 0, H - 1);     // the layer-3 border replicates FEATURE coordinates (:196-210)
             px_ = clampi_e(x + (int)(tap % 5u) - 2, 0, W - 1);
             wy0 = y - 6; wx0 = x - 6; wbase = (int)oo * 169; wpitch = 13;
@@ -433,8 +438,11 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
             for (unsigned e = tid; e < n_here * 169u; e += 256) {
                 const unsigned q = e / 169u, k = e % 169u;
                 const unsigned pq = p.scat[first + q];
-                const int yy = (int)(pq / (unsigned)W) - 6 + (int)(k / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(k % 13u);
-                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W) ywin[e] = (float)p.src[(long)(yy - p.src_row0) * p.src_stride + xx];
+                const unsigned fy = pq / (unsigned)W;                       // frame * H + y
+                const int fq = (int)(fy / (unsigned)H);
+                const int yy = (int)(fy % (unsigned)H) - 6 + (int)(k / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(k % 13u);
+                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
+                    ywin[e] = (float)p.src[(long)fq * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
             }
         }
         __syncthreads();
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                 }
                 temp = temp + b3;
                 const uint8_t q = (uint8_t)clampi_e((int)temp, 0, 255);
-                uint8_t *d = p.dst + (long)(y - p.dst_row0) * p.dst_stride + x;
+                uint8_t *d = p.dst + (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + x;
                 if (*d != q) { *d = q; atomicAdd(&s_changed, 1u); }
             }
         } else {
@@ -492,12 +500,15 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                 temp = temp + b3;
                 const uint8_t q = (uint8_t)clampi_e((int)temp, 0, 255);
                 const unsigned pix = p.scat[first + tid];
-                const long o = (long)((int)(pix / (unsigned)W) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
+                const unsigned fy = pix / (unsigned)W;
+                const long oin = (long)((int)(fy % (unsigned)H) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
+                const long o = (long)(fy / (unsigned)H) * p.dst_frame_pitch + oin;
+                const long of = (long)(fy / (unsigned)H) * p.flag_frame_pitch + oin;
                 // how far the MFMA path's value was from the reference's: v_mfma = rint(v) + (code's distance), rint(v) = the
                 // stored byte (+ 1 where v sat just below the integer).  The code resolves the distance to delta / 253, so a v
                 // AT an integer can decode to the other side of it: the difference is therefore taken modulo 1 (both
                 // values lie within delta << 0.5 of the same integer)
-                const float dist = ((float)p.flag[o] - 1.f) * p.code_step - p.delta;
+                const float dist = ((float)p.flag[of] - 1.f) * p.code_step - p.delta;
                 const float v_mfma = (float)p.dst[o] + (dist < 0.f ? 1.f : 0.f) + dist;
                 const float dev = v_mfma - temp;
                 atomicMax(&s_maxdev, __float_as_uint(fabsf(dev - rintf(dev))));
@@ -521,7 +532,7 @@ hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st)
     const int rows = p.row_end - p.row_begin;
     const int tiles_x = (p.width + FIX_TILE - 1) / FIX_TILE, bands = (rows + FIX_TILE - 1) / FIX_TILE;
     const int segs = (tiles_x + FIX_SEG_TILES - 1) / FIX_SEG_TILES;
-    hipLaunchKernelGGL(fix_collect_kernel, dim3((unsigned)(bands * segs)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(fix_collect_kernel, dim3((unsigned)(bands * segs * p.n_frames)), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // four workgroups per CU (128 VGPRs, 39 KB of LDS each) = all of them resident; they draw items from FIX_NEXT_ITEM

@@ -113,11 +113,15 @@ struct FixParams {
     long dst_stride;
     int dst_row0;
     int width, height, row_begin, row_end;
-    const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32]
+    const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32], then W1 transposed [81][64]
     unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel
     unsigned *totals;               // the same four, accumulated over every launch of the context (srcnn_fixup_stats)
-    unsigned *scat, *dense;         // work lists: pixel y * width + x; tile index
+    unsigned *scat, *dense;         // work lists: pixel (frame * height + y) * width + x; tile index frame * tiles + t
     float delta, code_step;         // code_step = 2 delta / 253
+    // one fix-up for the planes of several single-frame strip launches (srcnn_forward_y_dev): frame k of the batch lies at
+    // src + k * src_frame_pitch / dst + k * dst_frame_pitch / flag + k * flag_frame_pitch, same rows in every frame
+    int n_frames;
+    long src_frame_pitch, dst_frame_pitch, flag_frame_pitch;
 };
 // SRCNN_MODE_REFBYTES: the flag byte stored beside an output byte (srcnn_kernels.h, srcnn_exact.hip): 0, or 1 + the position of
 // v - rint(v) in [-delta, +delta] on a 253-step scale, for the values a rounding difference of the MFMA path could carry across
@@ -133,6 +137,7 @@ __device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
 }
 
 hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);
+constexpr int FIX_BATCH_FRAMES = 16;      // frames per fix-up launch at most (pixel codes stay below 2^32 up to 16 x 16384 x 16384)
 size_t fixup_list_entries(int width, int rows, size_t *dense_entries);
 
 // A SEAM is the boundary between two vertically adjacent work items of a strip.  Instead of recomputing the

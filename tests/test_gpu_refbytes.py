@@ -129,6 +129,37 @@ def test_batches_stripes_and_device_entry_points(ref_ctx, weights_blob):
     assert np.array_equal(res[:, :w], want[1]) and (res[:, w:] == 9).all()
 
 
+def test_fixup_batches_span_frames_with_any_pitch(ref_ctx, weights_blob):
+    """srcnn_forward_y_dev finishes up to 16 frames of a batch with ONE fix-up (pixel codes carry the frame; the lists, the flag
+    planes and the item draw are shared): 19 frames = a full batch and a partial one, frame pitches that are not width x height
+    and differ between input and output, a constant frame (dense tiles) between textured ones, a scattered group that straddles
+    two frames."""
+    import torch
+    w, h, n = 203, 119, 19
+    rng = np.random.default_rng(77)
+    frames = synth_batch(w, h, n, first_frame=3)
+    frames[4] = 38                                         # a flat 38 comes out at 37.99993: every interior tile is dense
+    frames[11] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    want = [oracle.forward_y(f, weights_blob)[0] for f in frames]
+    sp, dp, ss, ds = h * (w + 5) + 64, h * (w + 9) + 192, w + 5, w + 9
+    d_in = torch.zeros(n * sp, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        d_in[k * sp:k * sp + h * ss].view(h, ss)[:, :w] = torch.from_numpy(frames[k]).cuda()
+    d_out = torch.full((n * dp,), 5, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    before = ref_ctx.fixup_stats()
+    ref_ctx.forward_y_dev(d_in.data_ptr(), ss, sp, d_out.data_ptr(), ds, dp, w, h, n)
+    ref_ctx.synchronize()
+    st = ref_ctx.fixup_stats()
+    got = d_out.cpu().numpy()
+    for k in range(n):
+        plane = got[k * dp:k * dp + h * ds].reshape(h, ds)
+        assert np.array_equal(plane[:, :w], want[k]), k
+        assert (plane[:, w:] == 5).all() and (got[k * dp + h * ds:(k + 1) * dp] == 5).all(), k      # nothing outside the planes
+    assert st["dense_tiles"] - before["dense_tiles"] >= (w // 12 - 2) * (h // 12 - 2)            # the constant frame's interior
+    assert st["scattered_pixels"] > before["scattered_pixels"]
+
+
 def test_preclamp_request_gets_the_reference_float(ref_ctx, weights_blob):
     y = synth_luma(300, 70, frame=1)
     pre = np.empty(y.shape, np.float32)
