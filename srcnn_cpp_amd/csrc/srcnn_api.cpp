@@ -1012,7 +1012,7 @@ int frames_per_launch(const srcnn_ctx *c, int width, int height, int n_frames)
 {
     static const char *env_loop = std::getenv("SRCNN_DEBUG_FRAMELOOP");      // experiment knob: 0 = never one launch per frame
     const size_t px = (size_t)width * height;
-    if (c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16) return 1;       // the fix-up's work lists are per plane
+    if (c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16) return 1;       // flag planes are compact per frame; the FIX-UP spans up to FIX_BATCH_FRAMES of them (run_strip)
     if (c->mode != SRCNN_MODE_MFMA || n_frames <= 1) return kGridBatchChunk;
     if (!(env_loop && std::atoi(env_loop) == 0) &&
         ((px >= ((size_t)4 << 20) && n_frames < kItemBatchMax) || (px >= ((size_t)3 << 19) && n_frames <= 8)))
@@ -1814,9 +1814,12 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         p.row_begin = 0;
         p.row_end = height;
         const bool refbytes = c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16;      // (kMaxFrames is 1)
-        const int batch0 = f0 - f0 % FIX_BATCH_FRAMES;
+        // frames per fix-up: the work lists' 32-bit pixel codes (frame * height + y) * width + x must not wrap
+        const int fix_batch = (int)std::max<unsigned long long>(
+            1ull, std::min<unsigned long long>(FIX_BATCH_FRAMES, 0xffffffffull / ((unsigned long long)width * height)));
+        const int batch0 = f0 - f0 % fix_batch;
         if ((rc = run_strip(c, MODE_FUSED, p, std::min(kMaxFrames, n_frames - f0), refbytes ? f0 - batch0 : 0,
-                            refbytes ? std::min(FIX_BATCH_FRAMES, n_frames - batch0) : 1)))
+                            refbytes ? std::min(fix_batch, n_frames - batch0) : 1)))
             return rc;
     }
     return SRCNN_OK;

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Profiles of one round on ONE MI355X (run through gpurun from the repo root):
 #   tools/profile_round.sh [OUTDIR]        (default gpurun_out/prof)
+#   PMC_ONLY=1 tools/profile_round.sh [OUTDIR]   only steps 2-3 (kernel trace + PMC passes + summary): what profiles/pmc_traffic.json
+#                                                needs after a change of the launch code that leaves the kernels alone
 # 1. the default bench line (with cpu_baseline), 2. rocprofv3 --kernel-trace --stats of the same command,
 # 3. PMC passes (one counter group per run, never together with a trace), for the float32 MFMA mode and
 # for the opt-in split-f16 mode, 4. the other configurations (tools/measure_all.sh), 5. in-kernel stamps.
@@ -9,6 +11,7 @@ OUT=${1:-gpurun_out/prof}
 ROOT=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ -z "$PMC_ONLY" ]; then
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2>> $OUT/bench_default.err      # the driver's exact command
 python bench.py --mode refbytes --no-cpu-baseline > $OUT/bench_refbytes.json 2>> $OUT/bench_default.err
@@ -16,6 +19,7 @@ python bench.py --mode refbytes --frames 64 --steps 5 --no-cpu-baseline > $OUT/b
 python bench.py --mode refbytes16 --no-cpu-baseline > $OUT/bench_refbytes16.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --no-cpu-baseline > $OUT/bench_split16.json 2>> $OUT/bench_default.err
 python bench.py --mode split16 --frames 64 --steps 10 --no-cpu-baseline > $OUT/bench_split16_b64.json 2>> $OUT/bench_default.err
+fi
 for mode in mfma split16; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$mode -o trace -- \
       python3 $ROOT/bench.py --mode $mode --steps 20 --warmup 3 --no-cpu-baseline ) > $OUT/trace_$mode.log 2>&1
@@ -27,6 +31,7 @@ for mode in mfma split16; do
         python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline ) > $OUT/pmc_${mode}_$tag.log 2>&1
   done
 done
+if [ -z "$PMC_ONLY" ]; then
 # Convolution99x11 (<1>) and Convolution55 (<2>) alone: HBM bytes (FETCH_SIZE x2, WRITE_SIZE: pmc_calibration.txt) and instruction mix
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
   tag=$(echo $grp | cut -d' ' -f1)
@@ -53,6 +58,7 @@ python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
 [ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
 [ -x build/mfma_probe ] && ./build/mfma_probe > $OUT/mfma_probe.txt 2>&1
 [ -x build/pk_f32_probe ] && ./build/pk_f32_probe > $OUT/pk_f32_probe.txt 2>&1
+fi
 # keep the merge small: the raw per-dispatch csv files are summarised on the box
 python tools/pmc_summarize.py $OUT > $OUT/pmc_summarize.log 2>&1
 find $OUT -name "*counter_collection.csv" -size +2M -delete
