@@ -26,7 +26,7 @@ def dim(big):
     r = rng.random()
     if r < 0.5: return int(rng.choice(edges))
     return int(rng.integers(1, big))
-n = 0; worst = {"mfma": 0.0, "split16": 0.0}; t0 = time.time()
+n = 0; n_batches = 0; worst = {"mfma": 0.0, "split16": 0.0}; t0 = time.time()
 while time.time() - t0 < budget:
     w, h = dim(900), dim(700)
     if rng.random() < 0.1: h = int(rng.integers(1500, 6000)); w = int(rng.choice([124, 125, 248, 300]))   # item planner
@@ -63,6 +63,31 @@ while time.time() - t0 < budget:
         assert d.max() <= 1, (name, w, h, kind)
         if d.any():
             assert np.abs(r_pre - np.rint(r_pre))[d != 0].max() <= TOL * scale, (name, w, h, kind)
+    if n % 4 == 0:      # a batch of small planes through srcnn_forward_y_dev in a REFBYTES mode: ONE fix-up per 16 frames, odd pitches
+        bw, bh, nf = int(rng.integers(5, 260)), int(rng.integers(3, 160)), int(rng.integers(2, 22))
+        fr = []
+        for k in range(nf):
+            kk = rng.integers(0, 4)
+            fr.append(synth_luma(bw, bh, frame=int(rng.integers(0, 50))) if kk == 0 else
+                      rng.integers(0, 256, size=(bh, bw), dtype=np.uint8) if kk == 1 else
+                      np.full((bh, bw), int(rng.choice([38, 54, int(rng.integers(0, 256))])), np.uint8) if kk == 2 else
+                      np.where((np.add.outer(np.arange(bh) // 8, np.arange(bw) // 8) % 2) == 0, 16, 240).astype(np.uint8))
+        ss, ds = bw + int(rng.integers(0, 9)), bw + int(rng.integers(0, 9))
+        sp, dp = bh * ss + int(rng.integers(0, 100)), bh * ds + int(rng.integers(0, 100))
+        d_in = torch.zeros(nf * sp, dtype=torch.uint8, device="cuda")
+        for k in range(nf):
+            d_in[k * sp:k * sp + bh * ss].view(bh, ss)[:, :bw] = torch.from_numpy(fr[k]).cuda()
+        d_out = torch.full((nf * dp,), 7, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.set_mode(S.MODE_REFBYTES if (n // 4) % 2 == 0 else S.MODE_REFBYTES16)
+        ctx.forward_y_dev(d_in.data_ptr(), ss, sp, d_out.data_ptr(), ds, dp, bw, bh, nf)
+        ctx.synchronize()
+        got = d_out.cpu().numpy()
+        for k in range(nf):
+            plane = got[k * dp:k * dp + bh * ds].reshape(bh, ds)
+            assert np.array_equal(plane[:, :bw], oracle.forward_y(fr[k], blob)[0]), ("refbytes batch", bw, bh, nf, k)
+            assert (plane[:, bw:] == 7).all() and (got[k * dp + bh * ds:(k + 1) * dp] == 7).all(), ("wrote outside", bw, bh, nf, k)
+        n_batches += 1
     n += 1
 ctx.set_mode(S.MODE_MFMA)
 st = ctx.fixup_stats()
@@ -70,5 +95,5 @@ assert st["max_dev"] < 0.5 * st["delta"], st
 print(f"refbytes: every plane bytewise equal to the reference arithmetic; {st['scattered_pixels']} pixels recomputed one by one, "
       f"{st['dense_tiles']} tiles whole, {st['bytes_changed']} bytes changed; largest |v_mfma - v_ref| seen {st['max_dev']:.2e} "
       f"against delta {st['delta']:.2e}")
-print(f"soak ok: {n} random planes in {time.time() - t0:.0f} s (seed {seed}); worst pre-clamp error / max(1, |ref|max/255): "
+print(f"soak ok: {n} random planes and {n_batches} REFBYTES batches of 2-21 frames in {time.time() - t0:.0f} s (seed {seed}); worst pre-clamp error / max(1, |ref|max/255): "
       f"mfma {worst['mfma']:.2e}, split16 {worst['split16']:.2e}")
