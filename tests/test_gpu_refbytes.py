@@ -90,6 +90,41 @@ def test_full_4k_frame_has_the_oracle_sha(ref_ctx, weights_blob):
     assert 0 < st["max_dev"] < 0.5 * st["delta"], st            # the margin: |v_fast - v_ref| seen on the flagged sample
 
 
+_ORACLE_8K = {}
+
+
+def test_configs3_plane_and_its_540_row_stripes(ref_ctx, weights_blob):
+    """BASELINE configs[3]'s plane (7680 x 4320, 33 MPix) in the REFBYTES modes: one launch on device memory, the host entry
+    point (row bands with overlapped transfers, one fix-up per band) and the 8 x 540-row stripes of the multi-GPU split each
+    from its own halo-extended rows -- every byte equal to the reference arithmetic (computed once on the host's cores)."""
+    import torch
+    w, h = 7680, 4320
+    y = synth_luma(w, h)
+    if "out" not in _ORACLE_8K:
+        _ORACLE_8K["out"] = oracle.forward_y(y, weights_blob)[0]
+    want = _ORACLE_8K["out"]
+    d_in = torch.from_numpy(y).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ref_ctx.forward_y_dev(d_in.data_ptr(), w, 0, d_out.data_ptr(), w, 0, w, h, 1)
+    ref_ctx.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), want), "one launch"
+    assert np.array_equal(ref_ctx.forward_y(y), want), "host entry point (row bands)"
+    out = np.zeros_like(y)
+    for k in range(8):
+        r0, r1 = 540 * k, 540 * (k + 1)
+        s0, s1 = max(0, r0 - 6), min(h, r1 + 6)
+        d_s = d_in[s0:s1].contiguous()
+        d_o = torch.zeros((540, w), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ref_ctx.forward_y_rows_dev(d_s.data_ptr(), w, s0, d_o.data_ptr(), w, r0, w, h, r0, r1)
+        ref_ctx.synchronize()
+        out[r0:r1] = d_o.cpu().numpy()
+    assert np.array_equal(out, want), "8 x 540-row stripes"
+    st = ref_ctx.fixup_stats()
+    assert 0 < st["max_dev"] < 0.5 * st["delta"], st
+
+
 def test_batches_stripes_and_device_entry_points(ref_ctx, weights_blob):
     import torch
     w, h, n = 1920, 1080, 5
