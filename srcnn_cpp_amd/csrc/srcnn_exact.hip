@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         // addresses per item through the CU's one texture path against ~1,700 here).  Scattered pixel o: the 13 x 13 image
         // window around it at ywin[o * 169]; dense tile: the 24 x 24 window around the tile.  Elements outside the image (or
         // beyond the rows a stripe's caller provides) are never read: every read address is a CLAMPED coordinate.  The buffer
-        // aliases Fs, which is written only after every lane holds its window in registers.
+        // aliases Fs, which is written only after every lane has finished layers 1-2 (barrier below).
         float *ywin = &Fs[0][0];
         int py, px_;                             // this lane's feature position (clamped image coordinates)
         int wy0, wx0, wbase, wpitch;             // origin (image coordinates), LDS base and pitch of the window this lane reads
