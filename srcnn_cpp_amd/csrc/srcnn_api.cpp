@@ -1186,16 +1186,15 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         int rc;
         if ((rc = seam_scratch_for_stream(c, &fsc))) return rc;
         const int rows = p.row_end - p.row_begin;
-        fix_scat_cap = fixup_list_entries(p.width, rows, &fix_dense_cap) * (size_t)fix_frames;
-        fix_dense_cap *= (size_t)fix_frames;
+        fix_scat_cap = fixup_list_entries(p.width, rows, fix_frames, &fix_dense_cap);
         fix_flag_pitch = (size_t)rows * (size_t)p.dst_stride;
         // (sized for the whole batch at its first frame: no buffer moves while earlier frames' flags wait for the fix-up)
         if ((rc = reserve(c, fsc->flag, fix_flag_pitch * (size_t)fix_frames))) return rc;
         if ((rc = reserve(c, fsc->fix_lists, (fix_scat_cap + fix_dense_cap) * sizeof(unsigned)))) return rc;
         if ((rc = reserve(c, fsc->fix_counters, FIX_COUNTERS * sizeof(unsigned)))) return rc;
         if (!c->fix_totals.p) {
-            if ((rc = reserve(c, c->fix_totals, FIX_COUNTERS * sizeof(unsigned)))) return rc;
-            HIP_TRY(c, hipMemsetAsync(c->fix_totals.p, 0, FIX_COUNTERS * sizeof(unsigned), c->stream));
+            if ((rc = reserve(c, c->fix_totals, FIX_TOTALS * sizeof(unsigned)))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->fix_totals.p, 0, FIX_TOTALS * sizeof(unsigned), c->stream));
         }
         // flag[o] for the same element offsets o as dst: o >= (row_begin - dst_row0) * dst_stride
         p.flag = static_cast<uint8_t *>(fsc->flag.p) + (size_t)fix_frame * fix_flag_pitch - (long)(p.row_begin - p.dst_row0) * p.dst_stride;
@@ -1569,7 +1568,7 @@ int srcnn_fixup_stats(srcnn_ctx *c, unsigned long long out[4], float *delta, flo
 {
     BIND(c);
     if (!out) return fail(c, SRCNN_ERR_INVALID, "fixup_stats: null output");
-    unsigned t[FIX_COUNTERS] = {0, 0, 0, 0};
+    unsigned t[FIX_TOTALS] = {0, 0, 0, 0};
     if (c->fix_totals.p) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipMemcpy(t, c->fix_totals.p, sizeof(t), hipMemcpyDeviceToHost));

@@ -309,8 +309,16 @@ __device__ __forceinline__ int nz_bytes(unsigned dw)
 // bytes x 12 rows, read coalesced: 768 B per row) and adds its count to its tile's (t / 3) counter in LDS; tiles are then
 // classified, the flagged pixels of the scattered ones collected in an LDS list, and ONE reservation per workgroup made in
 // each global list (a returning atomic on one word sustains ~88 per microsecond chip-wide: one per tile would cost a
-// 3840x2160 plane 0.6 ms).  Rows that are not dword aligned (odd strides) are read byte by byte.
+// 3840x2160 plane 0.6 ms; even one per workgroup is 10 us of it, so the lists come in FIX_REGIONS regions with a word each).  Rows that are not dword aligned (odd strides) are read byte by byte.
 constexpr int FIX_SEG_TILES = 64, FIX_SEG_COLS = FIX_SEG_TILES * FIX_TILE;     // 768 columns = 192 dwords
+// Workgroups of fix_collect_kernel per list region (workgroup b fills region b % FIX_REGIONS): a region holds what they can
+// produce at most -- (FIX_DENSE_MIN - 1) scattered pixels and one dense tile per tile of a segment.
+__host__ __device__ inline unsigned fix_region_wgs(int width, int rows, int n_frames)
+{
+    const int tiles_x = (width + FIX_TILE - 1) / FIX_TILE, bands = (rows + FIX_TILE - 1) / FIX_TILE;
+    const int segs = (tiles_x + FIX_SEG_TILES - 1) / FIX_SEG_TILES;
+    return ((unsigned)(bands * segs * n_frames) + FIX_REGIONS - 1) / FIX_REGIONS;
+}
 __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
 {
     __shared__ unsigned s_cnt[FIX_SEG_TILES], s_scat[FIX_SEG_TILES * (FIX_DENSE_MIN - 1)], s_dense[FIX_SEG_TILES];
@@ -362,8 +370,11 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
     }
     __syncthreads();
     if (tid == 0) {
-        s_base_scat = s_nscat ? atomicAdd(&p.counters[FIX_N_SCAT], s_nscat) : 0u;
-        s_base_dense = s_ndense ? atomicAdd(&p.counters[FIX_N_DENSE], s_ndense) : 0u;
+        const unsigned region = blockIdx.x % FIX_REGIONS;     // neighbouring workgroups reserve on different words
+        unsigned *rc = p.counters + FIX_REGION0 + region * FIX_REGION_WORDS;
+        const unsigned rw = fix_region_wgs(p.width, p.row_end - p.row_begin, p.n_frames);
+        s_base_scat = region * rw * (FIX_SEG_TILES * (FIX_DENSE_MIN - 1)) + (s_nscat ? atomicAdd(rc, s_nscat) : 0u);
+        s_base_dense = region * rw * FIX_SEG_TILES + (s_ndense ? atomicAdd(rc + 32, s_ndense) : 0u);
     }
     __syncthreads();
     for (unsigned i = tid; i < s_nscat; i += 256) p.scat[s_base_scat + i] = s_scat[i];
@@ -383,8 +394,19 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     const int tid = threadIdx.x;
     for (int i = tid; i < 800; i += 256) s_w3[i] = p.wraw[7329 + i];
     if (tid == 0) { s_changed = 0; s_maxdev = 0; }
-    const unsigned n_dense = p.counters[FIX_N_DENSE], n_scat = p.counters[FIX_N_SCAT];
-    const unsigned n_items = n_dense + (n_scat + FIX_GROUP - 1) / FIX_GROUP;
+    // items: the dense tiles of regions 0 .. 7, then the groups of FIX_GROUP scattered pixels of regions 0 .. 7
+    unsigned nd[FIX_REGIONS], ns[FIX_REGIONS], n_dense = 0, n_scat = 0, n_groups = 0;
+#pragma unroll
+    for (int r = 0; r < FIX_REGIONS; ++r) {
+        ns[r] = p.counters[FIX_REGION0 + r * FIX_REGION_WORDS];
+        nd[r] = p.counters[FIX_REGION0 + r * FIX_REGION_WORDS + 32];
+        n_dense += nd[r];
+        n_scat += ns[r];
+        n_groups += (ns[r] + FIX_GROUP - 1) / FIX_GROUP;
+    }
+    const unsigned n_items = n_dense + n_groups;
+    const unsigned region_wgs = fix_region_wgs(p.width, p.row_end - p.row_begin, p.n_frames);
+    const unsigned scat_cap = region_wgs * (FIX_SEG_TILES * (FIX_DENSE_MIN - 1)), dense_cap = region_wgs * FIX_SEG_TILES;
     const int W = p.width, H = p.height;
     const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE, bands = (p.row_end - p.row_begin + FIX_TILE - 1) / FIX_TILE;
     const float b3 = p.wraw[7328];
@@ -409,8 +431,19 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         unsigned first = 0;
         // (rows beyond row_end + 5 feed no pixel of this launch: a row stripe's caller provides [row_begin - 6, row_end + 6))
         const int y_hi = min(H - 1, p.row_end + 5);
+        // the item's region and its index there (uniform)
+        unsigned idx = dense ? item : item - n_dense, reg = 0;
+#pragma unroll
+        for (int r = 0; r < FIX_REGIONS - 1; ++r) {
+            const unsigned here = dense ? nd[r] : (ns[r] + FIX_GROUP - 1) / FIX_GROUP;
+            if (reg == (unsigned)r && idx >= here) { idx -= here; reg = r + 1; }
+        }
+        unsigned n_reg = ns[0];                  // scattered pixels of the item's region
+#pragma unroll
+        for (int r = 1; r < FIX_REGIONS; ++r) n_reg = reg == (unsigned)r ? ns[r] : n_reg;
+        const unsigned *scat = p.scat + reg * scat_cap;
         if (dense) {
-            const unsigned t = p.dense[item];
+            const unsigned t = p.dense[reg * dense_cap + idx];
             const unsigned trow = t / (unsigned)tiles_x;                 // frame * bands + band
             frame = (int)(trow / (unsigned)bands);
             ty0 = p.row_begin + (int)(trow % (unsigned)bands) * FIX_TILE;
@@ -424,20 +457,20 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                     ywin[e] = (float)p.src[(long)frame * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
             }
         } else {
-            first = (item - n_dense) * FIX_GROUP;
+            first = idx * FIX_GROUP;
             const unsigned o = (unsigned)tid / 25u, tap = (unsigned)tid % 25u;
-            active = tid < FIX_GROUP * 25 && first + o < n_scat;
+            active = tid < FIX_GROUP * 25 && first + o < n_reg;
             // (idle lanes recompute the group's first pixel: any other coordinates could lie outside a row stripe's input)
             const unsigned oo = active ? o : 0u;
-            const unsigned pix = p.scat[first + oo];
+            const unsigned pix = scat[first + oo];
             const int y = (int)((pix / (unsigned)W) % (unsigned)H), x = (int)(pix % (unsigned)W);
             py = clampi_e(y + (int)(tap / 5u) - 2, 0, H - 1);     // the layer-3 border replicates FEATURE coordinates (:196-210)
             px_ = clampi_e(x + (int)(tap % 5u) - 2, 0, W - 1);
             wy0 = y - 6; wx0 = x - 6; wbase = (int)oo * 169; wpitch = 13;
-            const unsigned n_here = min((unsigned)FIX_GROUP, n_scat - first);
+            const unsigned n_here = min((unsigned)FIX_GROUP, n_reg - first);
             for (unsigned e = tid; e < n_here * 169u; e += 256) {
                 const unsigned q = e / 169u, k = e % 169u;
-                const unsigned pq = p.scat[first + q];
+                const unsigned pq = scat[first + q];
                 const unsigned fy = pq / (unsigned)W;                       // frame * H + y
                 const int fq = (int)(fy / (unsigned)H);
                 const int yy = (int)(fy % (unsigned)H) - 6 + (int)(k / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(k % 13u);
@@ -483,7 +516,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         } else {
             for (int round = 0; round < (FIX_GROUP + 7) / 8; ++round) {
                 const int o = tid / 32 + 8 * round, c = tid % 32;
-                if (o < FIX_GROUP && first + o < n_scat) {
+                if (o < FIX_GROUP && first + o < n_reg) {
                     double tp = 0.0;
 #pragma unroll
                     for (int tap = 0; tap < 25; ++tap) {
@@ -494,12 +527,12 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                 }
             }
             __syncthreads();
-            if (tid < FIX_GROUP && first + tid < n_scat) {
+            if (tid < FIX_GROUP && first + tid < n_reg) {
                 float temp = 0.f;
                 for (int c = 0; c < 32; ++c) temp = (float)((double)temp + s_tp[tid][c]);
                 temp = temp + b3;
                 const uint8_t q = (uint8_t)clampi_e((int)temp, 0, 255);
-                const unsigned pix = p.scat[first + tid];
+                const unsigned pix = scat[first + tid];
                 const unsigned fy = pix / (unsigned)W;
                 const long oin = (long)((int)(fy % (unsigned)H) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
                 const long o = (long)(fy / (unsigned)H) * p.dst_frame_pitch + oin;
@@ -540,11 +573,11 @@ hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st)
     return hipGetLastError();
 }
 
-size_t fixup_list_entries(int width, int rows, size_t *dense_entries)
+size_t fixup_list_entries(int width, int rows, int n_frames, size_t *dense_entries)
 {
-    const size_t tiles = (size_t)((width + FIX_TILE - 1) / FIX_TILE) * ((rows + FIX_TILE - 1) / FIX_TILE);
-    if (dense_entries) *dense_entries = tiles;
-    return tiles * (FIX_DENSE_MIN - 1);          // a tile with more flagged pixels than that is a dense item
+    const size_t wgs = (size_t)fix_region_wgs(width, rows, n_frames) * FIX_REGIONS;
+    if (dense_entries) *dense_entries = wgs * FIX_SEG_TILES;
+    return wgs * FIX_SEG_TILES * (FIX_DENSE_MIN - 1);     // a tile with more flagged pixels than that is a dense item
 }
 
 static inline dim3 px_grid(int w, int h, int n) { return dim3((w + 63) / 64, (h + 3) / 4, n); }

@@ -103,7 +103,13 @@ struct StripParams {
 };
 
 // ---- SRCNN_MODE_REFBYTES: fix-up of the pixels whose MFMA value lies within delta of a truncation boundary (srcnn_exact.hip)
-enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_NEXT_ITEM = 4, FIX_COUNTERS = 5 };
+// Per-launch counter words (zeroed by the strip kernel) and the context's running totals (words 0 .. FIX_TOTALS - 1 of another
+// buffer).  The work lists are filled in FIX_REGIONS regions, each with its own pair of reservation words 256 B apart: a
+// returning atomic on ONE word sustains ~88 per microsecond chip-wide, and fix_collect_kernel makes one reservation per
+// workgroup -- 900 of them on a 3840x2160 plane (one word: 16.3 us for the kernel, eight: 8.0).
+enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_NEXT_ITEM = 4, FIX_TOTALS = 5,
+       FIX_REGIONS = 8, FIX_REGION_WORDS = 64, FIX_REGION0 = 64,      // region r: [FIX_REGION0 + r * FIX_REGION_WORDS] scattered pixels, [+ 32] dense tiles
+       FIX_COUNTERS = FIX_REGION0 + FIX_REGIONS * FIX_REGION_WORDS };
 struct FixParams {
     const uint8_t *src;             // the launch's Y input, as the strip kernel reads it
     long src_stride;
@@ -116,7 +122,7 @@ struct FixParams {
     const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32], then W1 transposed [81][64]
     unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel
     unsigned *totals;               // the same four, accumulated over every launch of the context (srcnn_fixup_stats)
-    unsigned *scat, *dense;         // work lists: pixel (frame * height + y) * width + x; tile index frame * tiles + t
+    unsigned *scat, *dense;         // work lists in FIX_REGIONS equal regions: pixel (frame * height + y) * width + x; tile index
     float delta, code_step;         // code_step = 2 delta / 253
     // one fix-up for the planes of several single-frame strip launches (srcnn_forward_y_dev): frame k of the batch lies at
     // src + k * src_frame_pitch / dst + k * dst_frame_pitch / flag + k * flag_frame_pitch, same rows in every frame
@@ -138,7 +144,7 @@ __device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
 
 hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);
 constexpr int FIX_BATCH_FRAMES = 16;      // frames per fix-up launch at most (pixel codes stay below 2^32 up to 16 x 16384 x 16384)
-size_t fixup_list_entries(int width, int rows, size_t *dense_entries);
+size_t fixup_list_entries(int width, int rows, int n_frames, size_t *dense_entries);
 
 // A SEAM is the boundary between two vertically adjacent work items of a strip.  Instead of recomputing the
 // two feature rows either side of it (4 rows per item), the item above hands over its 12 vertical-chain

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 {
     static_assert(!FIX || (MODE == MODE_FUSED && !PRE && DIAG == 0), "flags belong to the production fused kernel");
     if constexpr (FIX) {     // the launch's fix-up counters (FixParams::counters) start at zero; the fix-up kernels run behind this one
-        if (blockIdx.x == 0 && threadIdx.x < FIX_COUNTERS) p.fix_counters[threadIdx.x] = 0u;
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < FIX_COUNTERS; i += 256) p.fix_counters[i] = 0u;
     }
     unsigned long long lt[4] = {0, 0, 0, 0};
     if constexpr (DIAG == 2) lt[0] = __builtin_amdgcn_s_memrealtime();

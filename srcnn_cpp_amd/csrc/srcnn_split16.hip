@@ -84,7 +84,8 @@ template <bool PRE, bool DIAG = false, bool FIX = false>
 __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripParams p)
 {
     if constexpr (FIX) {     // the launch's fix-up counters start at zero; the fix-up kernels run behind this one
-        if (blockIdx.x == 0 && threadIdx.x < FIX_COUNTERS) p.fix_counters[threadIdx.x] = 0u;
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < FIX_COUNTERS; i += 256) p.fix_counters[i] = 0u;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16 *ring = reinterpret_cast<_Float16 *>(smem);                  // [2 copies][2*YR][SP_RS]

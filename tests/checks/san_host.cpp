@@ -20,7 +20,7 @@ hipError_t launch_cseams(const StripParams &, int, hipStream_t) { return never()
 hipError_t launch_seams_merged(const StripParams &, int, const int *, const unsigned char *, int, hipStream_t) { return never(); }
 hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_fixup(const FixParams &, int, hipStream_t) { return never(); }
-size_t fixup_list_entries(int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
+size_t fixup_list_entries(int, int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv11_exact(const float *, long, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
