@@ -410,9 +410,11 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     const int W = p.width, H = p.height;
     const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE, bands = (p.row_end - p.row_begin + FIX_TILE - 1) / FIX_TILE;
     const float b3 = p.wraw[7328];
-    for (;;) {
+    // The first item of a workgroup is its own index, the later ones are drawn from the shared counter (which therefore counts
+    // from gridDim.x): 1,024 workgroups drawing at once would queue on the one word for 12 us (~88 returning atomics per us).
+    for (bool first_round = true;; first_round = false) {
         __syncthreads();                         // s_item's readers of the previous round are done (and the kernel's LDS set-up)
-        if (tid == 0) s_item = atomicAdd(&p.counters[FIX_NEXT_ITEM], 1u);
+        if (tid == 0) s_item = first_round ? blockIdx.x : gridDim.x + atomicAdd(&p.counters[FIX_NEXT_ITEM], 1u);
         __syncthreads();
         const unsigned item = s_item;
         if (item >= n_items) break;
