@@ -233,9 +233,13 @@ def parse_args():
                     help="frames: independent planes per rank, no collective, weak scaling (default); "
                          "stripe: ONE width x height plane row-striped over the ranks with a 6-row "
                          "point-to-point halo exchange per step, strong scaling (BASELINE configs[3])")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="stripe workload: wait for the halo before the one launch (default: interior rows first, "
-                         "the two 6-row edge bands after the exchange)")
+    ap.add_argument("--stripe-form", choices=["halo", "bands", "assemble"], default="halo",
+                    help="stripe workload, how a rank's step is launched: halo (default) = ONE launch on the stripe where it "
+                         "lies, the received 6-row halos in small buffers of their own that alternate from step to step, so the "
+                         "exchange of the next step overlaps this step's kernel (srcnn_forward_y_rows_halo_dev); bands = interior "
+                         "rows first, then the two 6-row edge bands behind the exchange (rounds 2-3); assemble = exchange into a "
+                         "[halo | stripe | halo] buffer, then one launch")
+    ap.add_argument("--no-overlap", action="store_true", help="stripe workload: the same as --stripe-form assemble")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed device wake-up BEFORE the W warm-up steps: the same step, repeated for this long.  An idle "
                          "MI355X needs ~20 launches (20-30 ms) of load to reach its steady clocks -- the first steps after "
@@ -348,8 +352,12 @@ def worker(args):
 
     stepper = None
     if stripe:      # band buffers, send views and the point-to-point op list are built ONCE (sharding.StripeStep)
+        form = "assemble" if args.no_overlap else args.stripe_form
+        if args.mode not in ("mfma", "refbytes") and form == "halo":
+            form = "bands"              # the split-f16 kernels read one buffer only
         stepper = sharding.StripeStep(d_in[0], d_out[0], H, world, rank, sharding.gpu_launch_rows(ctx), group=rccl,
-                                      overlap=not args.no_overlap, via_host=world > 1 and rccl is None)
+                                      overlap=form != "assemble", via_host=world > 1 and rccl is None,
+                                      launch_rows_halo=sharding.gpu_launch_rows_halo(ctx) if form == "halo" else None)
     host_out = np.empty_like(frames[0])
     host_frames = np.empty_like(frames) if args.path == "host" and F > 1 else None
     if args.path == "pipeline":
@@ -566,7 +574,8 @@ def worker(args):
             out["distributed"] = {"control_plane": "gloo", "rccl_world": rccl_world,
                                   "halo_transport": (("rccl send/recv" if rccl is not None else "host-staged (gloo)")
                                                      if stripe else "none (frames are independent)"),
-                                  "halo_overlap": bool(stripe and not args.no_overlap)}
+                                  "stripe_form": form if stripe else None,
+                                  "halo_overlap": bool(stripe and form != "assemble")}
         if args.mode in ("refbytes", "refbytes16"):
             out["fixup"] = ctx.fixup_stats()                  # accumulated over every launch of the run
         if args.mode == "refbytes16":
@@ -755,9 +764,17 @@ def worker_cxx(args):
         "per_rank_ms_per_step": [round(v, 4) for v in kern],
         "host_us_per_step": round(host_us, 2),
         "cold_start": cold,
-        "distributed": {"control_plane": "none (one process)", "halo_transport": "hipMemcpyPeerAsync" if stripe else "none (frames are independent)",
-                        "halo_overlap": bool(stripe)},
+        "distributed": {"control_plane": "none (one process)",
+                        "halo_transport": ({1: "copy kernel (contexts share a device)", 2: "hipMemcpyPeerAsync with peer access (xGMI)",
+                                            3: "hipMemcpyPeerAsync WITHOUT peer access: staged through host memory by the runtime"}
+                                           .get(max(c.halo_transport() for c in ctxs), "none (one stripe)")
+                                           if stripe else "none (frames are independent)"),
+                        "stripe_form": "halo" if stripe else None, "halo_overlap": bool(stripe)},
     }
+    if stripe and any(c.halo_transport() == 3 for c in ctxs):
+        # a link refused peer access: the rows crossed host memory -- not the configs[3] transport; say so like the Python path
+        out["degraded"] = True
+        out["degraded_why"] = "; ".join(sorted({c._lib.srcnn_last_error(c._h).decode() for c in ctxs if c.halo_transport() == 3}))
     emit_line(out)
     for c in ctxs:
         c.close()

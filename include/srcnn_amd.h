@@ -198,9 +198,11 @@ int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx,
 
 /* ONE width x height host plane row-striped over n_ctx contexts: context k
  * uploads only its own rows srcnn_stripe_rows(height, n_ctx, k), the 6 halo rows
- * per boundary travel device to device, the interior rows are launched while
- * those copies are in flight and the two 6-row edge bands after them.  The
- * result is bit-identical to srcnn_forward_y.  Needs height / n_ctx >= 6. */
+ * per boundary travel device to device into small buffers of their own, and each
+ * stripe is ONE launch behind them (srcnn_forward_y_rows_halo_dev); the halo
+ * buffers alternate from step to step, so the copies of the next step overlap
+ * this step's kernel.  The result is bit-identical to srcnn_forward_y.
+ * Needs height / n_ctx >= 6. */
 int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx,
                             const uint8_t *src, size_t src_stride,
                             uint8_t *dst, size_t dst_stride, int width, int height);
@@ -212,6 +214,11 @@ int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx,
 int srcnn_forward_y_striped_dev(srcnn_ctx *const *ctxs, int n_ctx,
                                 const uint8_t *const *d_stripes, size_t stripe_stride,
                                 uint8_t *const *d_out, size_t out_stride, int width, int height);
+
+/* How the last striped step of this context moved its halo rows: 0 = no striped step yet, 1 = neighbours on the same
+ * device (a copy kernel), 2 = peer access (direct xGMI copies), 3 = peer access REFUSED by a link: the runtime stages the
+ * rows through host memory -- correct, but not the transport BASELINE configs[3] names; srcnn_last_error() says which link. */
+int srcnn_halo_transport(const srcnn_ctx *ctx);
 
 /* ---- device-resident entry points (pointers are DEVICE memory) ------------- *
  * Asynchronous on the context's stream; the caller synchronises.               */
@@ -232,6 +239,18 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *ctx,
                              const uint8_t *d_src, size_t src_stride, int src_row0,
                              uint8_t *d_dst, size_t dst_stride, int dst_row0,
                              int width, int height, int row_begin, int row_end);
+
+/* The same stripe with its halo rows in SEPARATE device buffers, so that a rank's rows are used where they lie and the 6 rows
+ * received from each neighbour land in small buffers of their own (no copy of the stripe next to them, ONE launch per
+ * stripe): d_src holds image rows [src_row0, src_row0 + src_rows), d_halo_top rows [src_row0 - 6, src_row0), d_halo_bot
+ * rows [src_row0 + src_rows, + 6), both with row stride halo_stride (elements).  A halo pointer may be NULL when rows
+ * [row_begin - 6, row_end + 6) need nothing on that side (image edge).  float32 MFMA modes (SRCNN_MODE_MFMA, REFBYTES).
+ * Bit-identical to srcnn_forward_y_rows_dev on the assembled rows. */
+int srcnn_forward_y_rows_halo_dev(srcnn_ctx *ctx,
+                                  const uint8_t *d_src, size_t src_stride, int src_row0, int src_rows,
+                                  const uint8_t *d_halo_top, const uint8_t *d_halo_bot, size_t halo_stride,
+                                  uint8_t *d_dst, size_t dst_stride, int dst_row0,
+                                  int width, int height, int row_begin, int row_end);
 
 /* Materialising variant of the whole path (layer-1/2 kernel writes the 32
  * planar f32 maps to HBM, layer-3 kernel reads them back), n_frames planes.

@@ -41,7 +41,8 @@ def _cpu_has(*flags: str) -> bool:
 
 def build(force: bool = False) -> Path:
     """(Re)build liboracle with oracle/Makefile; generic x86-64 if no AVX2/FMA."""
-    srcs = [_HERE / "srcnn_oracle.c", _HERE / "srcnn_gpuorder.c", _HERE / "opencv_steps.c", _HERE / "Makefile"]
+    srcs = [_HERE / "srcnn_oracle.c", _HERE / "srcnn_gpuorder.c", _HERE / "opencv_steps.c", _HERE / "adversarial.c",
+            _HERE / "Makefile"]
     stale = (not _LIB_PATH.exists()) or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs)
     if force or stale:
         arch = "-mavx2 -mfma" if _cpu_has("avx2", "fma") else ""
@@ -74,6 +75,9 @@ def lib() -> C.CDLL:
         _lib.opencv_resize_cubic.argtypes = [_u8p, sz, i, i, _u8p, sz, i, i]
         _lib.opencv_resize_cubic_variant.argtypes = [_u8p, sz, i, i, _u8p, sz, i, i, i]
         _lib.opencv_scaled_dim.argtypes = [i, C.c_float]
+        _lib.srcnn_adv_point.argtypes = [_u8p, _f32p, _f32p, _f32p]
+        _lib.srcnn_adv_search.argtypes = [_f32p, _u8p, i, i, i, C.c_uint64, _u8p, _f32p, _f32p]
+        _lib.srcnn_adv_search.restype = C.c_long
     return _lib
 
 
@@ -263,3 +267,33 @@ def process_bgr(bgr, scale, blob, y_path=None, vertical=VERTICAL_SIMD_FLOAT):
     planes = [resize_cubic(p, ow, oh, vertical) for p in bgr2ycrcb(bgr)]
     y_sr, _ = (y_path or forward_y)(planes[0], blob)
     return ycrcb2bgr(y_sr, planes[1], planes[2])
+
+
+# ---- attack on the REFBYTES flag threshold (oracle/adversarial.c) ----
+
+def adv_point(win, blob):
+    """(v_ref, v_gpu) of the centre pixel of a 13 x 13 luma window: the reference's value before its truncating store
+    and the float32 MFMA kernels' value, each bit for bit what the whole-plane functions above give for that pixel."""
+    win, pw = _u8(win)
+    assert win.shape == (13, 13)
+    blob, pb = _f32(blob)
+    a, b = C.c_float(), C.c_float()
+    assert lib().srcnn_adv_point(pw, pb, C.byref(a), C.byref(b)) == 0
+    return float(a.value), float(b.value)
+
+
+def adv_search(starts, blob, iters, seed=1, scale_iters=0):
+    """Coordinate ascent on |v_gpu - v_ref| from every window of ``starts`` [n, 13, 13] (restarts run in parallel); the first
+    ``scale_iters`` moves of a restart climb on the magnitude of the layer-3 products instead.
+    -> (windows [n, 13, 13], deviation [n], values [n, 2] = (v_ref, v_gpu), point evaluations)."""
+    starts, ps = _u8(starts)
+    n = starts.shape[0]
+    assert starts.shape[1:] == (13, 13)
+    blob, pb = _f32(blob)
+    wins = np.empty_like(starts)
+    dev = np.empty(n, np.float32)
+    vals = np.empty((n, 2), np.float32)
+    evals = lib().srcnn_adv_search(pb, ps, n, int(iters), int(scale_iters), int(seed), wins.ctypes.data_as(_u8p),
+                                   dev.ctypes.data_as(_f32p), vals.ctypes.data_as(_f32p))
+    assert evals >= 0
+    return wins, dev, vals, int(evals)

@@ -105,6 +105,8 @@ def load_library() -> C.CDLL:
         "srcnn_forward_y_frames": ([vp, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
         "srcnn_forward_y_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
         "srcnn_forward_y_rows_dev": ([vp, vp, sz, i, vp, sz, i, i, i, i, i], i),
+        "srcnn_forward_y_rows_halo_dev": ([vp, vp, sz, i, i, vp, vp, sz, vp, sz, i, i, i, i, i], i),
+        "srcnn_halo_transport": ([vp], i),
         "srcnn_forward_y_unfused_dev": ([vp, vp, sz, sz, vp, sz, sz, i, i, i, vp], i),
         "srcnn_conv99x11_dev": ([vp, vp, sz, vp, sz, sz, i, i], i),
         "srcnn_conv55_dev": ([vp, vp, sz, sz, vp, sz, i, i, vp], i),
@@ -140,7 +142,7 @@ ABI_SYMBOLS = (
     "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_conv99", "srcnn_conv11",
     "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_frames",
     "srcnn_forward_y_dev",
-    "srcnn_forward_y_rows_dev", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
+    "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
     "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
@@ -384,6 +386,17 @@ class Context:
         self._check(self._lib.srcnn_forward_y_rows_dev(self._h, d_src, src_stride, src_row0, d_dst,
                                                        dst_stride, dst_row0, width, height,
                                                        row_begin, row_end))
+
+    def forward_y_rows_halo_dev(self, d_src, src_stride, src_row0, src_rows, d_halo_top, d_halo_bot, halo_stride,
+                                d_dst, dst_stride, dst_row0, width, height, row_begin, row_end):
+        """A row stripe with its 6 halo rows either side in buffers of their own (0 / None = no rows on that side)."""
+        self._check(self._lib.srcnn_forward_y_rows_halo_dev(self._h, d_src, src_stride, src_row0, src_rows,
+                                                            d_halo_top or None, d_halo_bot or None, halo_stride, d_dst,
+                                                            dst_stride, dst_row0, width, height, row_begin, row_end))
+
+    def halo_transport(self) -> int:
+        """0 none yet, 1 same device, 2 peer access (xGMI), 3 staged through the host (srcnn_halo_transport)."""
+        return int(self._lib.srcnn_halo_transport(self._h))
 
     def forward_y_unfused_dev(self, d_src, src_stride, src_frame_pitch, d_dst, dst_stride,
                               dst_frame_pitch, width, height, n_frames, d_work):

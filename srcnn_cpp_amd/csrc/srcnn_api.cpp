@@ -146,7 +146,7 @@ struct srcnn_ctx {
         bool separated = false;         // seam windows of neighbouring strips share no row: one seam launch (plan_items_balanced())
         unsigned long stamp = 0;        // last use, for eviction
     };
-    static constexpr int kItemTables = 8;
+    static constexpr int kItemTables = 32;
     ItemTable item_tables[kItemTables];
     unsigned long item_clock = 0;
     // host copy of the uploaded tables in convdata.h order: the per-call weight arguments of the reference surface
@@ -161,6 +161,17 @@ struct srcnn_ctx {
     hipEvent_t halo_ready = nullptr, bands_done = nullptr;
     bool bands_pending = false;
     DevBuf band_top, band_bot, stripe_ext;
+    // ... one-launch form (float32 MFMA kernel, StripParams::src_top).  With peer access (or neighbours on the same device) the
+    // kernel reads the neighbours' edge rows WHERE THEY LIE, over xGMI: no copy, no event.  Only when a link refuses peer
+    // access are the 6 halo rows either side copied (staged by the runtime) into buffers of their own, kHaloSets sets used in
+    // turn, so that the copies of a step run while the kernels of the steps before it still read the other sets;
+    // halo_free[i] = the launch that last read set i has finished
+    static constexpr int kHaloSets = 4;
+    DevBuf halo_top[kHaloSets], halo_bot[kHaloSets];
+    hipEvent_t halo_free[kHaloSets] = {nullptr, nullptr, nullptr, nullptr};
+    bool halo_free_set[kHaloSets] = {false, false, false, false};
+    unsigned long stripe_steps = 0;
+    int halo_transport = 0;                // srcnn_halo_transport(): 0 none yet, 1 same device, 2 peer access (xGMI), 3 staged by the runtime
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
@@ -469,6 +480,8 @@ size_t span_elems(size_t stride, size_t frame_pitch, int width, int height, int 
 {
     return (size_t)(n_frames - 1) * frame_pitch + (size_t)(height - 1) * stride + (size_t)width;
 }
+
+constexpr int kHaloRows = 6;   // 4 input rows of the 9x9 layer + 2 feature rows of the 5x5 layer
 
 struct Plan {
     int seg_rows, n_strips, n_segs;
@@ -1236,6 +1249,10 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         f.src = p.src - (long)fix_frame * p.src_frame_pitch;
         f.src_stride = p.src_stride;
         f.src_row0 = p.src_row0;
+        f.src_top = p.src_top;
+        f.src_bot = p.src_bot;
+        f.halo_stride = p.halo_stride;
+        f.src_row1 = p.src_row1;
         f.dst = p.dst - (long)fix_frame * p.dst_frame_pitch;
         f.flag = p.flag - (long)fix_frame * (long)fix_flag_pitch;
         f.dst_stride = p.dst_stride;
@@ -1489,6 +1506,11 @@ void srcnn_destroy(srcnn_ctx *c)
                       &c->bgr_in, &c->bgr_out, &c->ycc_lo, &c->ycc_hi, &c->y_sr, &c->tables, &c->wfrag16,
                       &c->band_top, &c->band_bot, &c->stripe_ext})
         release(*b);
+    for (int k = 0; k < srcnn_ctx::kHaloSets; ++k) {
+        release(c->halo_top[k]);
+        release(c->halo_bot[k]);
+        if (c->halo_free[k]) (void)hipEventDestroy(c->halo_free[k]);
+    }
     for (int k = 0; k < 2; ++k)
         if (c->pin_plane[k]) (void)hipHostFree(c->pin_plane[k]);
     if (c->halo_ready) (void)hipEventDestroy(c->halo_ready);
@@ -1841,6 +1863,46 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
     p.src = d_src;
     p.src_stride = (long)src_stride;
     p.src_row0 = src_row0;
+    p.dst = d_dst;
+    p.dst_stride = (long)dst_stride;
+    p.dst_row0 = dst_row0;
+    p.width = width;
+    p.height = height;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    return run_strip(c, MODE_FUSED, p, 1);
+}
+
+int srcnn_forward_y_rows_halo_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, int src_row0, int src_rows,
+                                  const uint8_t *d_halo_top, const uint8_t *d_halo_bot, size_t halo_stride,
+                                  uint8_t *d_dst, size_t dst_stride, int dst_row0, int width, int height,
+                                  int row_begin, int row_end)
+{
+    BIND(c);
+    if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
+    const int src_row1 = src_row0 + src_rows;
+    if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || src_rows <= 0 ||
+        row_begin < 0 || row_end > height || row_begin >= row_end || src_row0 < 0 || src_row1 > height ||
+        dst_row0 > row_begin || dst_row0 < 0 || ((d_halo_top || d_halo_bot) && halo_stride < (size_t)width) ||
+        halo_stride >= ((size_t)1 << 30))
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_rows_halo_dev: bad arguments");
+    // the 13x13 receptive field of rows [row_begin, row_end) must lie in top | src | bot
+    const int need0 = std::max(0, row_begin - kHaloRows), need1 = std::min(height, row_end + kHaloRows);
+    if ((need0 < src_row0 && (!d_halo_top || src_row0 < kHaloRows || need0 < src_row0 - kHaloRows)) ||
+        (need1 > src_row1 && (!d_halo_bot || need1 > src_row1 + kHaloRows)))
+        return fail(c, SRCNN_ERR_INVALID, "forward_y_rows_halo_dev: rows [%d,%d) need input rows [%d,%d); src holds [%d,%d) and "
+                                          "the halo buffers 6 rows either side", row_begin, row_end, need0, need1, src_row0, src_row1);
+    if (c->mode != SRCNN_MODE_MFMA && c->mode != SRCNN_MODE_REFBYTES)
+        return fail(c, SRCNN_ERR_STATE, "separate halo buffers are read by the float32 MFMA kernel only (SRCNN_MODE_MFMA / REFBYTES)");
+    StripParams p{};
+    p.src = d_src;
+    p.src_stride = (long)src_stride;
+    p.src_row0 = src_row0;
+    p.src_row1 = src_row1;
+    // a side the launch reads nothing from keeps a null pointer: with both null this is srcnn_forward_y_rows_dev
+    p.src_top = need0 < src_row0 ? d_halo_top : nullptr;
+    p.src_bot = need1 > src_row1 ? d_halo_bot : nullptr;
+    p.halo_stride = (long)halo_stride;
     p.dst = d_dst;
     p.dst_stride = (long)dst_stride;
     p.dst_row0 = dst_row0;
@@ -2375,7 +2437,52 @@ hipError_t copy_rows_between(srcnn_ctx *to, uint8_t *dst, size_t dst_stride, con
     return hipSuccess;
 }
 
+// The streams and events of the striped step, and the link to the neighbouring devices: peer access is asked for ONCE and the
+// answer kept -- a refused link still works (hipMemcpyPeerAsync then stages through host memory) but is not the xGMI path
+// BASELINE configs[3] names, so the context says so (srcnn_halo_transport(), srcnn_last_error()).
+int stripe_setup(srcnn_ctx *const *ctxs, int n_ctx, int k)
+{
+    srcnn_ctx *c = ctxs[k];
+    if (c->halo_stream) return SRCNN_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->bands_done, hipEventDisableTiming));
+    for (int i = 0; i < srcnn_ctx::kHaloSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->halo_free[i], hipEventDisableTiming));
+    c->halo_transport = 1;
+    static const char *env_staged = std::getenv("SRCNN_DEBUG_HALO_STAGED");      // test knob: take the no-peer-access path
+    if (env_staged && std::atoi(env_staged)) c->halo_transport = 3;
+    for (int n : {k - 1, k + 1}) {
+        if (n < 0 || n >= n_ctx || ctxs[n]->device == c->device) continue;
+        int can = 0;
+        hipError_t e = hipDeviceCanAccessPeer(&can, c->device, ctxs[n]->device);
+        if (e == hipSuccess && can) {
+            e = hipDeviceEnablePeerAccess(ctxs[n]->device, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        }
+        if (e == hipSuccess && can) {
+            c->halo_transport = std::max(c->halo_transport, 2);
+        } else {
+            (void)hipGetLastError();
+            c->halo_transport = 3;
+            (void)fail(c, SRCNN_OK, "row stripes: device %d has no peer access to device %d (%s): halo rows are staged through host "
+                                    "memory, not copied over xGMI", c->device, ctxs[n]->device,
+                       e == hipSuccess ? "hipDeviceCanAccessPeer says no" : hipGetErrorString(e));
+        }
+    }
+    return SRCNN_OK;
+}
+
 // One context's part of the striped step.  Runs on its own host thread (one thread per device).
+//
+// float32 MFMA kernel (SRCNN_MODE_MFMA / REFBYTES): ONE launch per stripe through srcnn_forward_y_rows_halo_dev -- the kernel
+// picks the buffer a Y row lives in with a scalar select.  With peer access (xGMI) or neighbours on the same device the halo
+// "buffers" ARE the neighbours' stripes: the 60 workgroups at a stripe edge load 46 KB of the neighbour's edge rows in their
+// prologue, straight over the link -- no copy, no second stream, no event, nothing on the critical path but the launch.
+// A link that refuses peer access gets copies (staged through the host by the runtime) into halo buffers of this device on
+// a second stream, kHaloSets sets in turn so that the copies of a step overlap the kernels of the steps before it.
+// The earlier form -- interior rows first, then two 6-row edge bands from [6 halo | 12 own] buffers: three strip launches,
+// up to three seam launches, four row copies -- paid 30-55 us for the band launches to hide a 15 us copy
+// (profiles/r04/stripe_projection.txt); it remains for the kernels that read one buffer only (split-f16 modes).
 int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const *d_stripes, size_t stripe_stride,
                  uint8_t *const *d_out, size_t out_stride, int width, int height)
 {
@@ -2388,15 +2495,29 @@ int striped_step(srcnn_ctx *const *ctxs, int n_ctx, int k, const uint8_t *const 
     if (has_bot) srcnn_stripe_rows(height, n_ctx, k + 1, &b0, &b1);
     if (!has_top && !has_bot)
         return srcnn_forward_y_rows_dev(c, d_stripes[k], stripe_stride, 0, d_out[k], out_stride, 0, width, height, 0, height);
-    if (!c->halo_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->bands_done, hipEventDisableTiming));
-        for (int n : {k - 1, k + 1})                // direct xGMI copies where the link allows; staged otherwise
-            if (n >= 0 && n < n_ctx && ctxs[n]->device != c->device) {
-                (void)hipDeviceEnablePeerAccess(ctxs[n]->device, 0);
-                (void)hipGetLastError();
-            }
+    if ((rc = stripe_setup(ctxs, n_ctx, k))) return rc;
+    if (c->mode == SRCNN_MODE_MFMA || c->mode == SRCNN_MODE_REFBYTES) {
+        const uint8_t *nb_top = has_top ? d_stripes[k - 1] + (size_t)(a1 - a0 - kHalo) * stripe_stride : nullptr;
+        const uint8_t *nb_bot = has_bot ? d_stripes[k + 1] : nullptr;
+        if (c->halo_transport != 3)       // the neighbours' rows where they lie (same device, or peer-mapped over xGMI)
+            return srcnn_forward_y_rows_halo_dev(c, d_stripes[k], stripe_stride, r0, r1 - r0, nb_top, nb_bot, stripe_stride,
+                                                 d_out[k], out_stride, r0, width, height, r0, r1);
+        const int set = (int)(c->stripe_steps++ % srcnn_ctx::kHaloSets);
+        const size_t halo_bytes = (size_t)kHalo * width;
+        if ((rc = reserve(c, c->halo_top[set], halo_bytes))) return rc;
+        if ((rc = reserve(c, c->halo_bot[set], halo_bytes))) return rc;
+        uint8_t *top = static_cast<uint8_t *>(c->halo_top[set].p), *bot = static_cast<uint8_t *>(c->halo_bot[set].p);
+        if (c->halo_free_set[set]) HIP_TRY(c, hipStreamWaitEvent(c->halo_stream, c->halo_free[set], 0));
+        if (has_top) HIP_TRY(c, copy_rows_between(c, top, width, ctxs[k - 1], nb_top, stripe_stride, width, kHalo, c->halo_stream));
+        if (has_bot) HIP_TRY(c, copy_rows_between(c, bot, width, ctxs[k + 1], nb_bot, stripe_stride, width, kHalo, c->halo_stream));
+        HIP_TRY(c, hipEventRecord(c->halo_ready, c->halo_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->halo_ready, 0));
+        if ((rc = srcnn_forward_y_rows_halo_dev(c, d_stripes[k], stripe_stride, r0, r1 - r0, has_top ? top : nullptr,
+                                                has_bot ? bot : nullptr, (size_t)width, d_out[k], out_stride, r0, width, height, r0, r1)))
+            return rc;
+        HIP_TRY(c, hipEventRecord(c->halo_free[set], c->stream));
+        c->halo_free_set[set] = true;
+        return SRCNN_OK;
     }
     const size_t band_bytes = (size_t)3 * kHalo * width;
     if ((rc = reserve(c, c->band_top, band_bytes))) return rc;
@@ -2526,6 +2647,8 @@ int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *sr
         return SRCNN_OK;
     });
 }
+
+int srcnn_halo_transport(const srcnn_ctx *c) { return c ? c->halo_transport : SRCNN_ERR_INVALID; }
 
 int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *src, size_t src_stride,
                                  uint8_t *const *dst, size_t dst_stride, int width, int height, int n_frames)

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
             for (int e = tid; e < (FIX_POS + 8) * (FIX_POS + 8); e += 256) {
                 const int yy = wy0 + e / (FIX_POS + 8), xx = wx0 + e % (FIX_POS + 8);
                 if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
-                    ywin[e] = (float)p.src[(long)frame * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
+                    ywin[e] = (float)fix_src_at(p, frame, yy, xx);
             }
         } else {
             first = idx * FIX_GROUP;
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                 const int fq = (int)(fy / (unsigned)H);
                 const int yy = (int)(fy % (unsigned)H) - 6 + (int)(k / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(k % 13u);
                 if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
-                    ywin[e] = (float)p.src[(long)fq * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
+                    ywin[e] = (float)fix_src_at(p, fq, yy, xx);
             }
         }
         __syncthreads();

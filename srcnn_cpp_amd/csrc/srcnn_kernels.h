@@ -72,6 +72,12 @@ struct StripParams {
     const uint8_t *src;
     long src_stride, src_frame_pitch;
     int src_row0;
+    // Row stripes with their halo rows in SEPARATE buffers (srcnn_forward_y_rows_halo_dev, single frame): src holds image
+    // rows [src_row0, src_row1), src_top rows [src_row0 - 6, src_row0), src_bot rows [src_row1, src_row1 + 6), both with
+    // row stride halo_stride.  Either may be null when the launch reads no row on that side.  Both null: src holds every row.
+    const uint8_t *src_top, *src_bot;
+    long halo_stride;
+    int src_row1;
     // layer-3 input (MODE_L3) / layer-2 output (MODE_L12): 32 planes in one allocation
     const float *planes_in;
     float *planes_out;
@@ -114,6 +120,9 @@ struct FixParams {
     const uint8_t *src;             // the launch's Y input, as the strip kernel reads it
     long src_stride;
     int src_row0;
+    const uint8_t *src_top, *src_bot;   // halo rows in separate buffers (StripParams::src_top), or null
+    long halo_stride;
+    int src_row1;
     uint8_t *dst;                   // the launch's output plane (already written by the strip and seam kernels)
     const uint8_t *flag;            // flag plane, same offsets as dst
     long dst_stride;
@@ -140,6 +149,14 @@ __device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
     const bool live = (__builtin_fabsf(dist) <= delta) & ((__builtin_bit_cast(unsigned, v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
     const unsigned code = (unsigned)((dist + delta) * scale + 1.5f);
     return live ? (uint8_t)code : (uint8_t)0;
+}
+
+// luma of image row yy, column xx of frame `frame`, wherever the launch keeps that row
+__device__ __forceinline__ uint8_t fix_src_at(const FixParams &p, int frame, int yy, int xx)
+{
+    if (p.src_top && yy < p.src_row0) return p.src_top[(long)(yy - (p.src_row0 - 6)) * p.halo_stride + xx];
+    if (p.src_bot && yy >= p.src_row1) return p.src_bot[(long)(yy - p.src_row1) * p.halo_stride + xx];
+    return p.src[(long)frame * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
 }
 
 hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);

@@ -126,6 +126,16 @@ __device__ __forceinline__ __attribute__((address_space(1))) T *scalar_base(T *p
     return g;
 }
 
+// A pointer every lane holds the same value of, moved to scalar registers explicitly (two v_readfirstlane_b32) where the
+// compiler's divergence analysis cannot see that it is uniform.
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 // Row barrier.  The waves of a workgroup only exchange data through LDS, so the barrier has to
 // order LDS traffic only: __syncthreads() would also wait for every outstanding global store and
 // load (s_waitcnt vmcnt(0)) on every row, which stalls MODE_L12 behind its 16 plane stores per row.
@@ -218,10 +228,14 @@ constexpr bool fast_kernel(int mode, bool pre, int diag)
 // (The timing-only ablation kernels of rounds 1-2 -- wrong pixels by construction -- and the per-row stamp build are gone
 // from this file; profiles/r02/ablation.txt names the commit that still has them.)
 // FIX: SRCNN_MODE_REFBYTES -- a flag byte beside every output byte (fix_code()).
-template <int MODE, bool PRE, int DIAG = 0, bool FIX = false>
+// HALO3: a row stripe whose 6 halo rows either side lie in buffers of their own (StripParams::src_top / src_bot): the Y row
+// address is a scalar select per row, nothing else changes -- one launch per stripe of a row-striped plane, no band launches
+// and no copy of the stripe next to its halo rows.
+template <int MODE, bool PRE, int DIAG = 0, bool FIX = false, bool HALO3 = false>
 __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
 {
     static_assert(!FIX || (MODE == MODE_FUSED && !PRE && DIAG == 0), "flags belong to the production fused kernel");
+    static_assert(!HALO3 || (MODE == MODE_FUSED && !PRE && DIAG == 0), "halo buffers belong to the production fused kernel");
     if constexpr (FIX) {     // the launch's fix-up counters (FixParams::counters) start at zero; the fix-up kernels run behind this one
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < FIX_COUNTERS; i += 256) p.fix_counters[i] = 0u;
@@ -337,9 +351,16 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     // (include/srcnn_amd.h, srcnn_forward_y_rows_dev): the ring slots behind y_last hold copies of that row, which
     // nothing consumes.
     const int y_last = min(H - 1, f_hi + 3);
+    // start of image row r (uniform, already clamped to the rows the launch may read)
+    auto y_row = [&](int r) -> const uint8_t * {
+        if constexpr (HALO3) {
+            if (r < p.src_row0) return p.src_top + (long)(r - (p.src_row0 - 6)) * p.halo_stride;
+            if (r >= p.src_row1) return p.src_bot + (long)(r - p.src_row1) * p.halo_stride;
+        }
+        return srcf + (long)(r - p.src_row0) * p.src_stride;
+    };
     auto load_y = [&](int r) -> uint8_t {
-        const int rr = clampi(r, 0, y_last) - p.src_row0;
-        const uint8_t *row = srcf + (long)rr * p.src_stride;      // uniform: scalar base + the lane's column
+        const uint8_t *row = y_row(clampi(r, 0, y_last));         // uniform: scalar base + the lane's column
         return row[(unsigned)ycol];
     };
     auto stage_y = [&](int r, uint8_t v) {
@@ -588,8 +609,13 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
             // here would make the compiler wait for the load right away)
             unsigned ynext;
             asm volatile("" : "=v"(ynext));      // (undefined in the lanes that load nothing: no instruction)
-            if (tid < YP) ynext = scalar_base(srcf + o_src)[lane_off((unsigned)ycol)];       // Y row min(f + 5, y_last)
-            if (f + 5 < y_last) o_src += p.src_stride;
+            if constexpr (HALO3) {
+                const uint8_t *yr = uniform_ptr(y_row(min(f + 5, y_last)));      // a few scalar instructions per row
+                if (tid < YP) ynext = scalar_base(yr)[lane_off((unsigned)ycol)];
+            } else {
+                if (tid < YP) ynext = scalar_base(srcf + o_src)[lane_off((unsigned)ycol)];       // Y row min(f + 5, y_last)
+                if (f + 5 < y_last) o_src += p.src_stride;
+            }
 
             // ---------------- layer 1: 82 MFMA ------------------------------
             const float *yb = ylds + ((f - 4) & (YR - 1)) * YP + xi;
@@ -987,7 +1013,12 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
     const bool pre = p.pre != nullptr;
     switch (mode) {
     case MODE_FUSED:
-        if (p.flag) {
+        if (p.src_top || p.src_bot) {
+            if (pre || (p.tune & 16) || n_frames != 1) return hipErrorInvalidValue;
+            if (p.flag) hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, true, true>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, false, true>), grid, block, lds, stream, p);
+        }
+        else if (p.flag) {
             if (pre) return hipErrorInvalidValue;       // (the API runs pre-clamp requests of that mode on the exact kernels)
             hipLaunchKernelGGL((srcnn_strip_kernel<MODE_FUSED, false, 0, true>), grid, block, lds, stream, p);
         }

@@ -28,6 +28,7 @@ from __future__ import annotations
 from typing import Callable, List, Optional, Tuple
 
 HALO_ROWS = 6   # 4 (9x9 layer) + 0 (1x1) + 2 (5x5 layer)
+HALO_SETS = 4   # halo tensors of the one-launch stripe step, used in turn (StripeStep)
 
 
 def split_range(n: int, parts: int, index: int) -> Tuple[int, int]:
@@ -179,6 +180,20 @@ def gpu_launch_rows(ctx) -> Callable:
     return run
 
 
+def gpu_launch_rows_halo(ctx) -> Callable:
+    """launch_rows_halo(src, src_row0, top, bot, out, dst_row0, height, row_begin, row_end): the stripe where it lies, its 6
+    halo rows either side in tensors of their own (None at an image edge) -- srcnn_forward_y_rows_halo_dev, ONE launch."""
+    def run(src, src_row0, top, bot, out, dst_row0, height, row_begin, row_end):
+        if not (src.is_cuda and out.is_cuda):
+            raise RuntimeError("the HIP path needs device tensors (no CPU fallback)")
+        halo = top if top is not None else bot
+        ctx.forward_y_rows_halo_dev(src.data_ptr(), src.stride(0), src_row0, src.shape[0],
+                                    top.data_ptr() if top is not None else 0, bot.data_ptr() if bot is not None else 0,
+                                    halo.stride(0) if halo is not None else src.shape[1],
+                                    out.data_ptr(), out.stride(0), dst_row0, src.shape[1], height, row_begin, row_end)
+    return run
+
+
 def band_plan(height: int, world: int, rank: int):
     """Split of this rank's output rows [r0, r1) for the overlapped stripe step:
     (interior [i0, i1), top band or None, bottom band or None).  The interior rows need only the rank's
@@ -204,20 +219,27 @@ class StripeStep:
     stripe / out : uint8 tensors [r1-r0, W], this rank's rows of the input / output plane; the SAME tensors
                    every step (refill ``stripe`` in place for a new plane).  ``stripe`` must be contiguous: its
                    first / last 6 rows are sent as they lie.
-    overlap      : post the 6-row exchange, launch the INTERIOR rows (which need no halo) while it is in
-                   flight, then the two 6-row edge bands; otherwise (or for stripes thinner than 18 rows)
+    launch_rows_halo : given, the step is ONE launch on the stripe where it lies with the received halo rows in two small
+                   tensors of their own (``gpu_launch_rows_halo``; the float32 MFMA kernel picks the buffer a row lives in).
+                   The halo tensors come in HALO_SETS sets used in turn, and on the GPU the exchange is posted on a side
+                   stream: the exchange of a step runs while the kernels of the steps before it still read the other sets.
+                   This is the default form of ``bench.py --workload stripe``: the band form below pays ~55 us for its two
+                   6-row band launches to hide a ~15 us exchange (profiles/r04/stripe_projection.txt).
+    overlap      : (without launch_rows_halo) post the 6-row exchange, launch the INTERIOR rows (which need no halo)
+                   while it is in flight, then the two 6-row edge bands; otherwise (or for stripes thinner than 18 rows)
                    exchange into a persistent [halo | stripe | halo] buffer and launch once.  Same bytes either
                    way: any partition of the rows computes the same plane (tests/test_sharding_gloo.py).
     via_host     : stage the halo rows through host memory (gloo group; smoke tests on a shared GPU).
     """
 
     def __init__(self, stripe, out, height: int, world: int, rank: int, launch_rows: Callable, group=None,
-                 overlap: bool = True, via_host: bool = False):
+                 overlap: bool = True, via_host: bool = False, launch_rows_halo: Optional[Callable] = None):
         import torch
         import torch.distributed as dist
 
         self.stripe, self.out, self.height, self.world, self.rank = stripe, out, height, world, rank
         self.launch_rows, self.group, self.via_host = launch_rows, group, via_host
+        self.launch_rows_halo, self.n_steps = launch_rows_halo, 0
         self.r0, self.r1 = stripe_rows(height, world, rank)
         if stripe.shape[0] != self.r1 - self.r0 or out.shape != stripe.shape:
             raise ValueError(f"rank {rank}: stripe has {stripe.shape[0]} rows, owns [{self.r0},{self.r1})")
@@ -233,6 +255,29 @@ class StripeStep:
         dev, width, rows = stripe.device, stripe.shape[1], self.r1 - self.r0
         has_top, has_bot = rank > 0, rank < world - 1
         self.s0, self.s1 = halo_extent(height, self.r0, self.r1)
+        if launch_rows_halo is not None:
+            # HALO_SETS sets of halo tensors and of everything that refers to them
+            self.sets = []
+            for _ in range(HALO_SETS):
+                top = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=dev) if has_top else None
+                bot = torch.empty((HALO_ROWS, width), dtype=stripe.dtype, device=dev) if has_bot else None
+                send_stage, recv_stage, ops = [], [], []
+
+                def endpoint(view, sending, send_stage=send_stage, recv_stage=recv_stage):
+                    if not via_host:
+                        return view
+                    host = torch.empty(view.shape, dtype=view.dtype)
+                    (send_stage if sending else recv_stage).append((view, host))
+                    return host
+                if has_top:
+                    ops += [dist.P2POp(dist.irecv, endpoint(top, False), rank - 1, group),
+                            dist.P2POp(dist.isend, endpoint(stripe[:HALO_ROWS], True), rank - 1, group)]
+                if has_bot:
+                    ops += [dist.P2POp(dist.isend, endpoint(stripe[rows - HALO_ROWS:], True), rank + 1, group),
+                            dist.P2POp(dist.irecv, endpoint(bot, False), rank + 1, group)]
+                self.sets.append(dict(top=top, bot=bot, ops=ops, send_stage=send_stage, recv_stage=recv_stage, free=None))
+            self.side = torch.cuda.Stream(device=dev) if (stripe.is_cuda and not via_host) else None
+            return
         if self.plan is None:          # one launch on [halo | stripe | halo]
             self.ext = torch.empty((self.s1 - self.s0, width), dtype=stripe.dtype, device=dev)
             recv_top = self.ext[:HALO_ROWS] if has_top else None
@@ -278,6 +323,8 @@ class StripeStep:
         if self.world == 1:
             self.launch_rows(stripe, 0, out, 0, h, 0, h)
             return out
+        if self.launch_rows_halo is not None:
+            return self._step_halo()
         if self.plan is None:
             reqs = self._post()
             top_n = r0 - self.s0
@@ -299,14 +346,43 @@ class StripeStep:
             self.launch_rows(self.bot_buf, r1 - 2 * HALO_ROWS, out, r0, h, bot[0], bot[1])
         return out
 
+    def _step_halo(self):
+        """ONE launch: exchange into this step's halo set, then the whole stripe (see the class docstring)."""
+        import torch
+        import torch.distributed as dist
+
+        st = self.sets[self.n_steps % HALO_SETS]
+        self.n_steps += 1
+        for view, host in st["send_stage"]:
+            host.copy_(view)
+        if self.side is not None:
+            # the exchange waits only for the launch that last read THIS set (HALO_SETS steps ago), not for the previous steps:
+            # its kernels need a free compute unit and find one in the tail of an earlier step's launch (same-box timing,
+            # tools/stripe_projection.py --diag: with two sets the hand-over cost 34 us per step, most of it this wait)
+            if st["free"] is not None:
+                self.side.wait_event(st["free"])
+            with torch.cuda.stream(self.side):
+                reqs = dist.batch_isend_irecv(st["ops"])
+        else:
+            reqs = dist.batch_isend_irecv(st["ops"])
+        for req in reqs:
+            req.wait()                 # NCCL / RCCL: orders the CURRENT stream behind the exchange, not the host
+        for view, host in st["recv_stage"]:
+            view.copy_(host)
+        self.launch_rows_halo(self.stripe, self.r0, st["top"], st["bot"], self.out, self.r0, self.height, self.r0, self.r1)
+        if self.side is not None:
+            st["free"] = torch.cuda.current_stream().record_event()
+        return self.out
+
     __call__ = step
 
 
 def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,
-                           group=None, overlap: bool = True, via_host: bool = False):
+                           group=None, overlap: bool = True, via_host: bool = False, launch_rows_halo: Optional[Callable] = None):
     """One row-striped step of ONE plane (a ``StripeStep`` built and run once; callers that step repeatedly keep
     the ``StripeStep``).  Returns ``out``."""
-    return StripeStep(stripe, out, height, world, rank, launch_rows, group=group, overlap=overlap, via_host=via_host).step()
+    return StripeStep(stripe, out, height, world, rank, launch_rows, group=group, overlap=overlap, via_host=via_host,
+                      launch_rows_halo=launch_rows_halo).step()
 
 
 def gather_stripes(out, height: int, world: int, rank: int, dst: int = 0, group=None):

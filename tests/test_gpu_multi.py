@@ -42,15 +42,17 @@ def test_bench_two_ranks_frames_equal_one_rank():
     assert two["value"] > 0 and two["roofline"]["frac"] > 0
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_bench_two_ranks_stripe_equal_one_rank(overlap):
-    """configs[3] shape: one plane, two ranks, 6-row halo exchange; the stitched plane equals the 1-rank plane."""
+@pytest.mark.parametrize("form", ["halo", "bands", "assemble"])
+def test_bench_two_ranks_stripe_equal_one_rank(form):
+    """configs[3] shape: one plane, two ranks, 6-row halo exchange; the stitched plane equals the 1-rank plane, whichever way
+    a rank launches its step (one launch with the halo rows in buffers of their own -- the default --, interior rows + edge
+    bands, or one launch on an assembled copy)."""
     w, h = 1920, 1080
     one = run_bench("--gpus", 1, "--workload", "stripe", "--width", w, "--height", h)
     two = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--workload", "stripe", "--width", w, "--height", h,
-                    *([] if overlap else ["--no-overlap"]))
+                    *(["--no-overlap"] if form == "assemble" else ["--stripe-form", form]))
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
-    assert two["distributed"]["halo_overlap"] is overlap
+    assert two["distributed"]["stripe_form"] == form and two["distributed"]["halo_overlap"] is (form != "assemble")
     assert two["config"]["output_crc32"] == one["config"]["output_crc32"] and len(one["config"]["output_crc32"]) == 1
     # ... and it is the plane the model of the kernel's arithmetic predicts
     import zlib
@@ -98,6 +100,41 @@ def test_striped_dev_back_to_back(gpu_ctx, ctx_pool):
     for p, step_out in zip(planes, d_out):
         got = np.concatenate([t.cpu().numpy() for t in step_out], axis=0)
         assert np.array_equal(got, gpu_ctx.forward_y(p))
+
+
+def test_striped_step_reports_its_halo_transport(gpu_ctx, ctx_pool):
+    """Contexts that share a device read each other's edge rows where they lie (transport 1; with peer access over xGMI it
+    would be 2) -- no copy.  A link that refuses peer access (transport 3) is not an error, but the context says so
+    (srcnn_halo_transport, srcnn_last_error): the copy path -- four halo buffer sets in turn on a second stream -- is forced
+    here in a fresh process and must give the same bytes over many back-to-back steps."""
+    y = synth_luma(700, 300, frame=4)
+    S.forward_y_striped(ctx_pool[:3], y)
+    assert [c.halo_transport() for c in ctx_pool[:3]] == [1, 1, 1]
+    code = (
+        "import numpy as np, torch, zlib, srcnn_cpp_amd as S\n"
+        "from srcnn_cpp_amd.synth import synth_luma\n"
+        "blob = S.load_weights(); ctxs = [S.Context(0) for _ in range(3)]\n"
+        "[c.set_weights_blob(blob) for c in ctxs]\n"
+        "w, h = 700, 300\n"
+        "crcs = []\n"
+        "rows = [S.stripe_rows(h, 3, k) for k in range(3)]\n"
+        "for f in range(11):\n"
+        "    y = synth_luma(w, h, frame=f)\n"
+        "    ins = [torch.from_numpy(np.ascontiguousarray(y[a:b])).cuda() for a, b in rows]\n"
+        "    outs = [torch.zeros_like(t) for t in ins]\n"
+        "    torch.cuda.synchronize()\n"
+        "    for _ in range(3): S.forward_y_striped_dev(ctxs, [t.data_ptr() for t in ins], w, [t.data_ptr() for t in outs], w, w, h)\n"
+        "    [c.synchronize() for c in ctxs]\n"
+        "    crcs.append(zlib.crc32(np.concatenate([t.cpu().numpy() for t in outs]).tobytes()))\n"
+        "print(crcs, [c.halo_transport() for c in ctxs], ctxs[1]._lib.srcnn_last_error(ctxs[1]._h).decode())\n")
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
+                       env=dict(os.environ, SRCNN_DEBUG_HALO_STAGED="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import zlib
+    want = [zlib.crc32(gpu_ctx.forward_y(synth_luma(700, 300, frame=f)).tobytes()) for f in range(11)]
+    assert r.stdout.strip().startswith(str(want)), r.stdout
+    assert "[3, 3, 3]" in r.stdout
 
 
 def test_frames_over_contexts_equal_single_context(gpu_ctx, ctx_pool):

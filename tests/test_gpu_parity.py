@@ -296,6 +296,58 @@ def test_row_stripes_equal_whole_image(gpu_ctx, weights_blob, n_stripes):
     assert np.array_equal(out, whole)
 
 
+@pytest.mark.parametrize("mode", [S.MODE_MFMA, S.MODE_REFBYTES])
+@pytest.mark.parametrize("w,h,n_stripes", [(260, 90, 2), (260, 90, 3), (260, 97, 8), (3840, 601, 3), (1000, 340, 4)])
+def test_row_stripes_with_halo_rows_in_their_own_buffers(weights_blob, mode, w, h, n_stripes):
+    """srcnn_forward_y_rows_halo_dev: a rank's rows where they lie (an exactly sized allocation), the 6 rows of each
+    neighbour in small buffers of their own with another row stride -- ONE launch per stripe, and the stitched plane is
+    the whole-image result bit for bit (the model's bytes in the MFMA mode, the reference's in SRCNN_MODE_REFBYTES).
+    3840x601 runs as work items with seams and the FAST row body, the small planes on the regular grid."""
+    torch = _torch()
+    y = synth_luma(w, h, frame=13)
+    want = oracle.gpuorder_forward_y(y, weights_blob)[0] if mode == S.MODE_MFMA else oracle.forward_y(y, weights_blob)[0]
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        ctx.set_mode(mode)
+        out = np.zeros_like(y)
+        for k in range(n_stripes):
+            r0, r1 = S.stripe_rows(h, n_stripes, k)
+            d_own = torch.from_numpy(np.ascontiguousarray(y[r0:r1])).cuda()
+            hs = w + 20                                             # the halo buffers' own row stride
+            top = bot = None
+            if k > 0:
+                top = torch.full((6, hs), 77, dtype=torch.uint8, device="cuda")
+                top[:, :w] = torch.from_numpy(np.ascontiguousarray(y[r0 - 6:r0])).cuda()
+            if k < n_stripes - 1:
+                bot = torch.full((6, hs), 77, dtype=torch.uint8, device="cuda")
+                bot[:, :w] = torch.from_numpy(np.ascontiguousarray(y[r1:r1 + 6])).cuda()
+            d_out = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctx.forward_y_rows_halo_dev(d_own.data_ptr(), w, r0, r1 - r0, top.data_ptr() if top is not None else 0,
+                                        bot.data_ptr() if bot is not None else 0, hs, d_out.data_ptr(), w, r0, w, h, r0, r1)
+            ctx.synchronize()
+            out[r0:r1] = d_out.cpu().numpy()
+        assert np.array_equal(out, want)
+        # a sub-range of a stripe that needs only ONE of the halos, and one that needs none (both pointers may then be null)
+        r0, r1 = S.stripe_rows(h, n_stripes, 1)
+        d_own = torch.from_numpy(np.ascontiguousarray(y[r0:r1])).cuda()
+        top = torch.from_numpy(np.ascontiguousarray(y[r0 - 6:r0])).cuda()
+        d_out = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        if r1 - r0 >= 14:
+            ctx.forward_y_rows_halo_dev(d_own.data_ptr(), w, r0, r1 - r0, top.data_ptr(), 0, w, d_out.data_ptr(), w, r0, w, h, r0, r1 - 6)
+            ctx.forward_y_rows_halo_dev(d_own.data_ptr(), w, r0, r1 - r0, 0, 0, w, d_out.data_ptr(), w, r0, w, h, r0 + 6, r1 - 6)
+            ctx.synchronize()
+            assert np.array_equal(d_out.cpu().numpy()[:r1 - r0 - 6], want[r0:r1 - 6])
+        # rows the buffers do not cover are refused, not read
+        with pytest.raises(S.SrcnnError) as e:
+            ctx.forward_y_rows_halo_dev(d_own.data_ptr(), w, r0, r1 - r0, 0, 0, w, d_out.data_ptr(), w, r0, w, h, r0, r1 - 6)
+        assert e.value.code == S.ERR_INVALID
+        if n_stripes > 2:
+            with pytest.raises(S.SrcnnError):
+                ctx.forward_y_rows_halo_dev(d_own.data_ptr(), w, r0, r1 - r0, top.data_ptr(), 0, w, d_out.data_ptr(), w, r0, w, h, r0, r1)
+
+
 @pytest.mark.parametrize("w,h", [(300, 97), (3840, 601)])
 def test_row_ranges_of_every_alignment(gpu_ctx, weights_blob, w, h):
     """The steady-state rows of a work item run through a row body that is unrolled over four rows and finishes two

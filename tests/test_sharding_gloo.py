@@ -48,6 +48,28 @@ def _oracle_launch_rows(blob):
     return run
 
 
+def _oracle_launch_rows_halo(blob):
+    """launch_rows_halo(src, src_row0, top, bot, out, dst_row0, height, rb, re) with srcnn_forward_y_rows_halo_dev semantics:
+    the stripe where it lies, 6 halo rows either side in tensors of their own (None at an image edge)."""
+    import oracle
+
+    def run(src, src_row0, top, bot, out, dst_row0, height, rb, re):
+        a, b = max(0, rb - 6), min(height, re + 6)
+        s1 = src_row0 + src.shape[0]
+        assert (a >= src_row0 or (top is not None and a >= src_row0 - 6)) and (b <= s1 or (bot is not None and b <= s1 + 6))
+        parts, base = [], src_row0
+        if a < src_row0:
+            parts.append(top.numpy())
+            base = src_row0 - 6
+        parts.append(src.numpy())
+        if b > s1:
+            parts.append(bot.numpy())
+        ext = np.concatenate(parts, axis=0)
+        res, _ = oracle.forward_y(ext[a - base:b - base], blob)
+        out[rb - dst_row0:re - dst_row0] = torch.from_numpy(res[rb - a:re - a])
+    return run
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,12 +92,18 @@ def _worker(rank, world, port, q):
             o = torch.zeros_like(mine)
             sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), overlap=overlap, via_host=via_host)
             outs.append(sharding.gather_stripes(o, H, world, rank))
+        for via_host in (False, True):        # ONE launch per stripe, halo rows in tensors of their own
+            o = torch.zeros_like(mine)
+            sharding.forward_striped_launch(mine, o, H, world, rank, _oracle_launch_rows(blob), via_host=via_host,
+                                            launch_rows_halo=_oracle_launch_rows_halo(blob))
+            outs.append(sharding.gather_stripes(o, H, world, rank))
         assert sharding.band_plan(H, world, rank) is not None
         # a persistent StripeStep (buffers and op lists built once) stepped on three different planes, refilled in place
         reuse_ok = True
-        for via_host in (False, True):
+        for via_host, halo in ((False, False), (True, False), (False, True), (True, True)):
             buf, o = mine.clone(), torch.zeros_like(mine)
-            stepper = sharding.StripeStep(buf, o, H, world, rank, _oracle_launch_rows(blob), via_host=via_host)
+            stepper = sharding.StripeStep(buf, o, H, world, rank, _oracle_launch_rows(blob), via_host=via_host,
+                                          launch_rows_halo=_oracle_launch_rows_halo(blob) if halo else None)
             for frame in (3, 8, 3):
                 p2 = synth_luma(W, H, frame=frame)
                 buf.copy_(torch.from_numpy(p2[r0:r1].copy()))
