@@ -261,6 +261,8 @@ def parse_args():
                          "cxx: ONE process drives --gpus contexts through the C ABI's several-GPUs entry points "
                          "(srcnn_forward_y_striped_dev: hipMemcpyPeerAsync halo copies, persistent host threads; frames: one "
                          "context per GPU, launches queued from one host thread) -- the second transport of the scaling curve")
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)        # another build of the library (tools/ab.sh, the tuning build)
+    ap.add_argument("--plpad", type=int, default=0, help=argparse.SUPPRESS)   # experiment: floats added to the unfused workspace's plane pitch (tuning build)
     ap.add_argument("--fault-rank", type=int, default=-1, help=argparse.SUPPRESS)      # test hook: this rank exits 7 before the rendezvous
     ap.add_argument("--shared-gpu", action="store_true",
                     help="smoke-test aid: every rank uses GPU 0 (1-GPU box, use with --backend gloo)")
@@ -273,6 +275,8 @@ def worker(args):
     import numpy as np
     import torch
     import srcnn_cpp_amd as S
+    if getattr(args, "lib", None):
+        S.use_library(args.lib)
     from srcnn_cpp_amd.synth import synth_batch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -347,7 +351,7 @@ def worker(args):
         frames = synth_batch(W, H, F, first_frame=rank * F)
     d_in = torch.from_numpy(frames).cuda()
     d_out = torch.zeros_like(d_in)
-    plpad = int(os.environ.get("SRCNN_DEBUG_PLPAD", "0"))           # experiment knob: see srcnn_forward_y_unfused_dev
+    plpad = args.plpad                                               # experiment knob: see srcnn_forward_y_unfused_dev
     d_work = torch.empty((F * 32 * (H * W + plpad),), dtype=torch.float32, device="cuda") if args.path == "unfused" else None
 
     stepper = None
@@ -662,6 +666,8 @@ def worker_cxx(args):
     import numpy as np
     import torch
     import srcnn_cpp_amd as S
+    if getattr(args, "lib", None):
+        S.use_library(args.lib)
     from srcnn_cpp_amd.synth import synth_batch, synth_luma
 
     n, W, H, F = args.gpus, args.width, args.height, args.frames

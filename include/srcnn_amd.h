@@ -76,8 +76,9 @@ enum {
  *                    integer (~0.4 % of them; delta is derived from the model), and
  *                    exactly those pixels are then recomputed in the reference's arithmetic
  *                    (src/srcnn.cpp:238-240 truncates: only there can rounding noise change a byte).
- *                    Output: bit-identical to the reference CPU path on every input tried; the
- *                    margin is observable (srcnn_fixup_stats).  The per-filter entry points and
+ *                    Output: bit-identical to the reference CPU path on every input tried, adversarially
+ *                    searched ones included; the guarantee is conditional on the monitored margin
+ *                    (srcnn_fixup_stats, srcnn_set_fixup_strict).  The per-filter entry points and
  *                    the materialising path run as in MFMA mode; a pre-clamp request runs the
  *                    exact kernels.
  *   SRCNN_MODE_REFBYTES16 opt-in, like SPLIT16 outside the float32 north star: the same flag-and-recompute
@@ -103,6 +104,13 @@ int srcnn_get_mode(const srcnn_ctx *ctx);
 int srcnn_set_stream(srcnn_ctx *ctx, void *hip_stream);
 /* Block until all work queued by this context has finished. */
 int srcnn_synchronize(srcnn_ctx *ctx);
+
+/* Which instantiation of the MFMA strip kernels this context launches: 0 = the fast one, whose row body relies on the
+ * hardware interlocking three MFMA <-> vector-ALU operand dependencies -- verified on this device by running exactly those
+ * instruction sequences with and without wait states at srcnn_create (once per device and process, ~1 ms); 1 = the
+ * hazard-safe one (every wait state the ISA manual asks for, ~3 % slower, the same bytes), chosen when that check fails;
+ * srcnn_last_error() then says so. */
+int srcnn_kernel_variant(const srcnn_ctx *ctx);
 
 /* ---- the reference call surface, host buffers ----------------------------- */
 
@@ -300,12 +308,25 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 
 /* ---- introspection for the bench / tests ---------------------------------- */
 
-/* SRCNN_MODE_REFBYTES: counters accumulated over the context's launches in that mode since creation.
+/* SRCNN_MODE_REFBYTES: counters accumulated over the context's launches in that mode since creation (64-bit on the device).
  * out[0] = pixels flagged and recomputed one by one, out[1] = 12x12 tiles recomputed whole (flat / periodic
- * content), out[2] = bytes the recomputation changed, out[3] = 0 (reserved); 32-bit counters on the device;
+ * content), out[2] = bytes the recomputation changed, out[3] = launches redone on the exact kernels in strict mode;
  * *delta = the flag threshold of the loaded model, *max_dev = the largest |v_mfma - v_reference| met on a
- * flagged pixel (a random ~0.4 % sample of all pixels): it must stay well below delta.  Synchronises the stream. */
+ * flagged pixel (a random ~0.4 % sample of all pixels).  Synchronises the stream.
+ *
+ * WHAT THE MODE GUARANTEES.  Its bytes are the reference's wherever |v_mfma - v_reference| <= delta.  delta is not a proven
+ * bound of that rounding noise (the rigorous one is ~10 grey levels): it is 6 x the noise scale of the loaded model,
+ * 4.6 x the largest deviation met on 54 MPix of content and 3.2 x the largest an adversarial search over receptive fields
+ * found (profiles/r04/fixup_adversarial.txt: 0.32 delta for the shipped model, <= 0.35 delta over 24 random models).  So the
+ * guarantee is CONDITIONAL on max_dev < delta, which the library lets a deployment watch and act on:
+ *   srcnn_set_fixup_strict(ctx, 1)  after every fix-up the host reads that launch's max_dev; above delta / 2 the launch's
+ *                                   frames are redone on the exact kernels (SRCNN_MODE_EXACT arithmetic on every pixel) and
+ *                                   counted in out[3].  One host synchronisation per fix-up (per <= 16 frames of a batch).
+ *   srcnn_set_fixup_margin(ctx, k)  delta = k x (noise scale) + the absolute term; default 6, range [0.25, 64].  The
+ *                                   fix-up's cost is linear in it (~0.12 ms per 1e-3 of delta on a 3840x2160 plane). */
 int srcnn_fixup_stats(srcnn_ctx *ctx, unsigned long long out[4], float *delta, float *max_dev);
+int srcnn_set_fixup_strict(srcnn_ctx *ctx, int on);
+int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
 
 /* Launch geometry the fused kernel would use for (width,height,n_frames):
  * out[0]=workgroups, out[1]=rows per segment (the tallest one when a single plane is cut into

@@ -26,18 +26,15 @@ from typing import Optional, Sequence
 import numpy as np
 
 __all__ = [
-    "Context", "SrcnnError", "load_library", "library_path", "load_weights", "split_weights",
+    "Context", "SrcnnError", "load_library", "library_path", "tuning_library_path", "use_library", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
     "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "MODE_REFBYTES16", "FLOP_PER_PIXEL",
     "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
     "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
 ]
 
-import os
-
 _PKG = Path(__file__).resolve().parent
-# SRCNN_LIB: an alternative build of the library for same-box A/B timing (tools/ab_build.sh); never set in production
-_LIB_PATH = Path(os.environ["SRCNN_LIB"]) if os.environ.get("SRCNN_LIB") else _PKG / "libsrcnn_amd.so"
+_LIB_PATH = _PKG / "libsrcnn_amd.so"              # the product library; use_library() for another build, before the first load
 _WEIGHTS_PATH = _PKG / "data" / "srcnn915_weights.f32"
 
 MODE_MFMA = 0
@@ -69,6 +66,21 @@ def library_path() -> Path:
     return _LIB_PATH
 
 
+def tuning_library_path() -> Path:
+    """The TUNING build of the library (srcnn_cpp_amd/build.py): the product's code plus the SRCNN_DEBUG_* experiment knobs
+    and the srcnn_debug_* test hooks, which the product library does not contain."""
+    return _PKG / "libsrcnn_amd_tuning.so"
+
+
+def use_library(path) -> None:
+    """Bind this process to another build of the library (the tuning build, an A/B variant of tools/ab.sh).  Explicit and
+    in-process: no environment variable redirects the binding.  Must be called before the first load."""
+    global _LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    _LIB_PATH = Path(path)
+
+
 def load_library() -> C.CDLL:
     """dlopen libsrcnn_amd.so; fails loudly when the HIP extension is missing."""
     global _lib
@@ -96,6 +108,7 @@ def load_library() -> C.CDLL:
         "srcnn_get_mode": ([vp], i),
         "srcnn_set_stream": ([vp, vp], i),
         "srcnn_synchronize": ([vp], i),
+        "srcnn_kernel_variant": ([vp], i),
         "srcnn_conv99": ([vp, _u8p, sz, _f32p, sz, i, i, _f32p, C.c_float], i),
         "srcnn_conv11": ([vp, _f32pp, sz, _f32p, sz, i, i, _f32p, C.c_float], i),
         "srcnn_conv55": ([vp, _f32pp, sz, _u8p, sz, i, i, _f32p, C.c_float], i),
@@ -118,6 +131,8 @@ def load_library() -> C.CDLL:
         "srcnn_dev_upload": ([vp, vp, vp, sz], i),
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
         "srcnn_fixup_stats": ([vp, C.POINTER(C.c_ulonglong * 4), C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
+        "srcnn_set_fixup_strict": ([vp, i], i),
+        "srcnn_set_fixup_margin": ([vp, C.c_float], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
         "srcnn_ycrcb2bgr": ([vp, _u8p, _u8p, _u8p, sz, i, i, _u8p, sz], i),
@@ -139,12 +154,12 @@ def load_library() -> C.CDLL:
 
 ABI_SYMBOLS = (
     "srcnn_abi_version", "srcnn_create", "srcnn_destroy", "srcnn_last_error", "srcnn_set_mode",
-    "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_conv99", "srcnn_conv11",
+    "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_kernel_variant", "srcnn_conv99", "srcnn_conv11",
     "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_frames",
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
-    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
@@ -250,6 +265,10 @@ class Context:
     def synchronize(self):
         self._check(self._lib.srcnn_synchronize(self._h))
 
+    def kernel_variant(self) -> int:
+        """0 = fast strip kernels (hardware interlock verified at create), 1 = hazard-safe kernels (srcnn_kernel_variant)."""
+        return int(self._lib.srcnn_kernel_variant(self._h))
+
     def set_weights(self, w1, b1, w2, b2, w3, b3):
         w1, b1 = _wt(w1, 5184, "kernel99"), _wt(b1, 64, "bias99")
         w2, b2 = _wt(w2, 2048, "kernel11"), _wt(b2, 32, "bias11")
@@ -307,7 +326,15 @@ class Context:
         out, delta, dev = (C.c_ulonglong * 4)(), C.c_float(), C.c_float()
         self._check(self._lib.srcnn_fixup_stats(self._h, C.byref(out), C.byref(delta), C.byref(dev)))
         return {"scattered_pixels": int(out[0]), "dense_tiles": int(out[1]), "bytes_changed": int(out[2]),
-                "delta": float(delta.value), "max_dev": float(dev.value)}
+                "exact_reruns": int(out[3]), "delta": float(delta.value), "max_dev": float(dev.value)}
+
+    def set_fixup_strict(self, on: bool = True):
+        """SRCNN_MODE_REFBYTES: redo a launch on the exact kernels when its monitored deviation exceeds delta / 2."""
+        self._check(self._lib.srcnn_set_fixup_strict(self._h, int(bool(on))))
+
+    def set_fixup_margin(self, factor: float):
+        """SRCNN_MODE_REFBYTES: delta = factor x (noise scale of the model) + absolute term; default 6."""
+        self._check(self._lib.srcnn_set_fixup_margin(self._h, float(factor)))
 
     # the two reference calls with the 32-plane map kept in device memory between them (include/srcnn_amd.h)
     def dev_alloc(self, nbytes: int) -> int:

@@ -1,0 +1,321 @@
+// srcnn_ctx.h -- what the host-side translation units of the C-ABI layer share: the context, error / device-scope helpers and
+// the declarations of the functions that cross a file boundary.  Not installed; the public boundary is include/srcnn_amd.h.
+//   srcnn_api.cpp     context life cycle, modes, streams, device memory, the REFBYTES monitor's entry points
+//   srcnn_model.cpp   weight tables: power-of-two layer scales, MFMA fragment packers, split-f16 ranges, the flag threshold
+//   srcnn_plan.cpp    launch geometry: regular grid, balanced work items and seams, item-table cache, srcnn_query_plan
+//   srcnn_launch.cpp  run_strip() -- the one launch path of the strip kernels and the fix-up -- and the device-pointer entry points
+//   srcnn_host.cpp    host-buffer entry points: staging, band / frame pipelines, the reference call surface, the pipeline steps
+//   srcnn_multi.cpp   several GPUs from one host process: row-striped plane, frame ranges
+#pragma once
+#include "../../include/srcnn_amd.h"
+#include "srcnn_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+// Experiment knobs (SRCNN_DEBUG_*, SRCNN_HOST_COPY_THREADS) and the srcnn_debug_* test hooks exist only in the TUNING build of
+// the library (-DSRCNN_TUNING_BUILD: libsrcnn_amd_tuning.so, which tools/ and the tests that need the hooks load by path).
+// The product library reads no environment variable and exports exactly the symbols of include/srcnn_amd.h
+// (tests/test_abi.py checks both on the built file).
+#ifdef SRCNN_TUNING_BUILD
+#define SRCNN_DEBUG_ENV(name) std::getenv(name)
+#else
+#define SRCNN_DEBUG_ENV(name) static_cast<const char *>(nullptr)
+#endif
+
+namespace srcnn {
+namespace host {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Persistent host threads of the several-GPUs entry points (srcnn_forward_y_striped*, srcnn_forward_y_frames_multi):
+// one worker per context beyond the first, created on first use and parked on a condition variable between calls.
+// Spawning and joining n_ctx - 1 std::threads PER STEP cost tens of microseconds next to 0.47 ms of kernel per rank for
+// a 7680x4320 plane on 8 GPUs.  Owned by the first context of the set (a context belongs to one host thread at a time,
+// include/srcnn_amd.h), destroyed with it.
+class WorkerPool {
+    struct Worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<int()> task;
+        bool has_task = false, done = false, stop = false;
+        int rc = 0;
+    };
+    std::vector<std::unique_ptr<Worker>> workers_;
+
+    static void loop(Worker *w)
+    {
+        std::unique_lock<std::mutex> lk(w->m);
+        for (;;) {
+            w->cv.wait(lk, [w] { return w->has_task || w->stop; });
+            if (w->stop) return;
+            std::function<int()> t = std::move(w->task);
+            w->has_task = false;
+            lk.unlock();
+            const int rc = t();
+            lk.lock();
+            w->rc = rc;
+            w->done = true;
+            w->cv.notify_all();
+        }
+    }
+
+public:
+    WorkerPool() = default;
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    ~WorkerPool()
+    {
+        for (auto &w : workers_) {
+            { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+    // fn(k) for k = 0 .. n - 1: k = 0 on the calling thread, the others on the parked workers; returns the first non-zero code
+    template <typename Fn>
+    int run(int n, Fn fn)
+    {
+        while ((int)workers_.size() < n - 1) {
+            workers_.emplace_back(new Worker());
+            Worker *w = workers_.back().get();
+            w->th = std::thread(loop, w);
+        }
+        for (int k = 1; k < n; ++k) {
+            Worker *w = workers_[(size_t)k - 1].get();
+            { std::lock_guard<std::mutex> lk(w->m); w->task = [&fn, k] { return fn(k); }; w->has_task = true; w->done = false; }
+            w->cv.notify_all();
+        }
+        int first = fn(0);
+        for (int k = 1; k < n; ++k) {
+            Worker *w = workers_[(size_t)k - 1].get();
+            std::unique_lock<std::mutex> lk(w->m);
+            w->cv.wait(lk, [w] { return w->done; });
+            if (!first && w->rc) first = w->rc;
+        }
+        return first;
+    }
+    int size() const { return (int)workers_.size(); }
+};
+
+}  // namespace host
+}  // namespace srcnn
+
+struct srcnn_ctx {
+    int device = 0;
+    int n_cu = 256;
+    int mode = SRCNN_MODE_MFMA;
+    bool safe_hazards = false;             // launch the hazard-safe strip kernels (the interlock probe failed on this device)
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = "no error";
+    // model
+    bool has_l12 = false, has_l3 = false;   // which layers of the uploaded tables came from the caller (the rest are zeros)
+    float b3 = 0.f;
+    srcnn::host::DevBuf wfrag;   // packed MFMA fragments [NFRAG][64]
+    srcnn::host::DevBuf wfrag16; // split-f16 fragments (SRCNN_MODE_SPLIT16), S16_TABLE_BYTES
+    bool split16_ok = false;   // the uploaded weights fit the f16 ranges of that mode (split16_range_ok)
+    srcnn::host::DevBuf wraw;    // b1|W1|b2|W2|b3|W3 in convdata.h order (exact kernels)
+    // staging for the host-buffer entry points
+    srcnn::host::DevBuf in_u8, out_u8, pre_f32, planes, plane1, kern, sink;
+    // seam scratch (srcnn_kernels.h) is written by one launch and read by the seam kernel behind it: one buffer per
+    // stream the context launches on (its own, the two frame lanes, a caller's), so launches on different
+    // streams never share it
+    struct SeamScratch {
+        hipStream_t stream = nullptr;
+        bool used = false;
+        srcnn::host::DevBuf buf, cbuf;           // row seams, column seams
+        srcnn::host::DevBuf flag, fix_lists, fix_counters;     // SRCNN_MODE_REFBYTES: flag plane, work lists, per-launch counters
+    };
+    SeamScratch seam_scratch[4];
+    // pipeline steps around the conv path
+    srcnn::host::DevBuf bgr_in, bgr_out, ycc_lo, ycc_hi, y_sr, tables;
+    int tab_sw = 0, tab_sh = 0, tab_dw = 0, tab_dh = 0;   // geometry the uploaded cubic tables are for
+    // second lane of the host-frame pipeline (srcnn_forward_y_frames)
+    // explicit work items of single-round launches (build_items): a small cache of device tables, one per
+    // launch geometry, so that a caller alternating between a few plane sizes never waits for an upload
+    struct ItemTable {
+        int key[7] = {0, 0, 0, 0, 0, 0, 0};
+        int count = 0;                  // 0: this geometry uses the regular grid
+        int n_seams = 0;
+        srcnn::host::DevBuf dev, dev_seams;
+        srcnn::host::DevBuf dev_winmap;              // [n_strips][rows] bytes: 1 = the row lies in a seam window of that strip (separated plans)
+        bool separated = false;         // seam windows of neighbouring strips share no row: one seam launch (plan_items_balanced())
+        unsigned long stamp = 0;        // last use, for eviction
+    };
+    static constexpr int kItemTables = 32;
+    ItemTable item_tables[kItemTables];
+    unsigned long item_clock = 0;
+    // host copy of the uploaded tables in convdata.h order: the per-call weight arguments of the reference surface
+    // (srcnn_conv99x11 / srcnn_conv55) are compared against it, and equal tables are not packed or uploaded again
+    std::vector<float> host_raw = std::vector<float>(8129, 0.f);
+    // pinned staging of the reference surface's 32 planes (two slots, alternating) and of single planes
+    void *pin_plane[2] = {nullptr, nullptr};
+    size_t pin_plane_cap = 0;
+    // row-striped multi-device step (srcnn_forward_y_striped*): second stream for the halo copies, band inputs
+    // [6 halo rows | 12 own rows] / [12 own rows | 6 halo rows], events ordering the two streams
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t halo_ready = nullptr, bands_done = nullptr;
+    bool bands_pending = false;
+    srcnn::host::DevBuf band_top, band_bot, stripe_ext;
+    // ... one-launch form (float32 MFMA kernel, StripParams::src_top).  With peer access (or neighbours on the same device) the
+    // kernel reads the neighbours' edge rows WHERE THEY LIE, over xGMI: no copy, no event.  Only when a link refuses peer
+    // access are the 6 halo rows either side copied (staged by the runtime) into buffers of their own, kHaloSets sets used in
+    // turn, so that the copies of a step run while the kernels of the steps before it still read the other sets;
+    // halo_free[i] = the launch that last read set i has finished
+    static constexpr int kHaloSets = 4;
+    srcnn::host::DevBuf halo_top[kHaloSets], halo_bot[kHaloSets];
+    hipEvent_t halo_free[kHaloSets] = {nullptr, nullptr, nullptr, nullptr};
+    bool halo_free_set[kHaloSets] = {false, false, false, false};
+    unsigned long stripe_steps = 0;
+    int halo_transport = 0;                // srcnn_halo_transport(): 0 none yet, 1 same device, 2 peer access (xGMI), 3 staged by the runtime
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    srcnn::host::DevBuf lane_in[2], lane_out[2];
+    void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
+    size_t pin_cap = 0;
+    float fix_delta = 0.f;                 // SRCNN_MODE_REFBYTES: flag threshold for the uploaded model (fixup_delta())
+    float fix_margin = 6.f;                // ... the factor of its weight-proportional term (srcnn_set_fixup_margin)
+    bool fix_strict = false;               // ... act on the monitor: a launch whose max_dev > delta / 2 is redone on the exact kernels
+    unsigned long long fix_reruns = 0;     // ... how many launches that happened to (srcnn_fixup_stats out[3])
+    srcnn::host::DevBuf fix_totals;                     // ... and its counters accumulated over the context's launches (srcnn_fixup_stats)
+    std::unique_ptr<srcnn::host::WorkerPool> pool;      // host threads of the several-GPUs calls this context leads (WorkerPool)
+};
+
+namespace srcnn {
+namespace host {
+
+int fail(srcnn_ctx *c, int code, const char *fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? SRCNN_ERR_NOMEM : SRCNN_ERR_HIP,     \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                         \
+    } while (0)
+
+// Every entry point makes the context's device current for its own duration and puts the caller's device
+// back on return (a framework sharing the thread keeps ITS current device).
+struct DeviceScope {
+    int prev = -1, rc = SRCNN_OK;
+    explicit DeviceScope(srcnn_ctx *c)
+    {
+        if (!c) { rc = SRCNN_ERR_INVALID; return; }
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) {
+            const hipError_t e = hipSetDevice(c->device);
+            if (e != hipSuccess) {
+                rc = fail(c, SRCNN_ERR_HIP, "hipSetDevice(%d) failed: %s", c->device, hipGetErrorString(e));
+                prev = -1;
+            }
+        } else {
+            prev = -1;      // nothing to restore
+        }
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define BIND(c)                 \
+    DeviceScope dev_scope_(c);  \
+    if (dev_scope_.rc) return dev_scope_.rc
+
+int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes);
+void release(DevBuf &b);
+
+constexpr int kHaloRows = 6;   // 4 input rows of the 9x9 layer + 2 feature rows of the 5x5 layer
+
+// ---- srcnn_model.cpp ----
+float fixup_delta(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, double margin = 6.0);
+void pack_fragments(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, float *out);
+void pack_fragments16(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, uint8_t *out);
+bool split16_range_ok(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3);
+int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float *k11, const float *b11, const float *k55, float b55);
+int use_layers12(srcnn_ctx *c, const float *kernel99, const float *bias99, const float *kernel11, const float *bias11);
+int use_layer3(srcnn_ctx *c, const float *kernel, float bias);
+inline bool has_model(const srcnn_ctx *c) { return c->has_l12 && c->has_l3; }
+extern const char *const kNoModel;
+
+// ---- srcnn_plan.cpp ----
+struct Plan {
+    int seg_rows, n_strips, n_segs;
+};
+Plan make_plan(const srcnn_ctx *c, int width, int rows, int n_frames, int halo, int wgs_per_cu = 2, int col_halo = -1);
+// Explicit work items for a launch that fits the GPU in ONE round with two workgroups per CU.
+// The hardware hands the first n_cu blocks wave slot 0 of every CU; the MFMA pipe is arbitrated by
+// age, so those run faster than the block that joins them later (tools/diag_stamps.py).  Exactly
+// 2*n_cu items are made: every strip is cut into k or k+1 segments, the "fast" ones (first n_cu
+// blocks) (1+skew) tall, the "slow" ones (1-skew) tall, so that all slots are used and the two
+// workgroups of a CU finish together.  Placement only affects speed; the items tile the rows exactly.
+// With ONE workgroup per CU (the pipelined split-f16 kernel) there are n_cu items of plain equal height
+// per strip.  With `want_seams` the boundaries between the items of a strip become seams
+// (srcnn_kernels.h): the items carry the ids of the seams above / below them, `seams` lists
+// {strip, boundary row} per id.  `items` holds ITEM_INTS ints per block in block order; empty when the
+// geometry does not qualify (the regular grid is used instead).
+struct ItemPlan {
+    std::vector<int> items, seams;
+    bool separated = false;        // no two seams of neighbouring strips closer than SEAM_ROWS rows (plan_items_balanced())
+    int count() const { return (int)items.size() / ITEM_INTS; }
+    int n_seams() const { return (int)seams.size() / 2; }
+};
+ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2, bool want_seams = false);
+int skew_percent();
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
+                const srcnn_ctx::ItemTable **table);
+int split16_wgs_per_cu(bool split16, int tune);
+int seam_scratch_for_stream(srcnn_ctx *c, srcnn_ctx::SeamScratch **out);
+bool cseam_pays(int width);
+constexpr int kItemBatchMax = 32, kItemBatchChunk = 8, kGridBatchChunk = 64;
+bool f32_mfma(const srcnn_ctx *c);
+int frames_per_launch(const srcnn_ctx *c, int width, int height, int n_frames);
+
+// ---- srcnn_launch.cpp ----
+bool ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes);
+size_t span_elems(size_t stride, size_t frame_pitch, int width, int height, int n_frames);
+bool bad_plane(const void *p, size_t stride, int w, int h);
+bool bad_pitch(size_t plane_pitch);
+int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame = 0, int fix_frames = 1);
+
+// ---- srcnn_host.cpp ----
+void cubic_table(int n_src, int n_dst, int *ofs, short *coef);
+
+// rows of `width` elements between a packed buffer and a strided one, split over a few threads
+template <typename T>
+void copy_rows_mt(T *dst, size_t dst_stride, const T *src, size_t src_stride, int width, int height)
+{
+    static const int n_thr = [] {
+        const char *e = SRCNN_DEBUG_ENV("SRCNN_HOST_COPY_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(1, e ? std::atoi(e) : std::min(8, hw > 0 ? hw / 2 : 4));
+    }();
+    auto part = [=](int y0, int y1) {
+        if (dst_stride == (size_t)width && src_stride == (size_t)width)
+            std::memcpy(dst + (size_t)y0 * width, src + (size_t)y0 * width, (size_t)(y1 - y0) * width * sizeof(T));
+        else
+            for (int y = y0; y < y1; ++y) std::memcpy(dst + (size_t)y * dst_stride, src + (size_t)y * src_stride, (size_t)width * sizeof(T));
+    };
+    const int nt = (int)std::min<size_t>((size_t)n_thr, std::max<size_t>(1, (size_t)width * height * sizeof(T) >> 20));   // >= 1 MB per thread
+    if (nt <= 1) { part(0, height); return; }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(part, (int)((long)height * t / nt), (int)((long)height * (t + 1) / nt));
+    part(0, height / nt);
+    for (auto &th : pool) th.join();
+}
+
+}  // namespace host
+}  // namespace srcnn

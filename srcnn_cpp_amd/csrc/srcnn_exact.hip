@@ -196,24 +196,26 @@ __global__ __launch_bounds__(256) void conv99x11_exact_kernel(const uint8_t *__r
                                                               float *__restrict__ planes, long stride,
                                                               long pitch, long frame_pitch, int w, int h,
                                                               const float *__restrict__ weights,
-                                                              const float *__restrict__ w2t)
+                                                              const float *__restrict__ w2t,
+                                                              int row0, int row1, int src_row0, int pl_row0)
 {
+    // rows [row0, row1) of the map; src points at image row src_row0, planes at map row pl_row0 (whole planes: 0, h, 0, 0)
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int row = row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     const int frame = blockIdx.z;
-    if (row >= h) return;
+    if (row >= row1) return;
     const uint8_t *sf = src + (long)frame * src_frame_pitch;
     float px[81];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        const uint8_t *sr = sf + (long)clampi_e(row + i - 4, 0, h - 1) * sstride;
+        const uint8_t *sr = sf + (long)(clampi_e(row + i - 4, 0, h - 1) - src_row0) * sstride;
 #pragma unroll
         for (int j = 0; j < 9; ++j) px[i * 9 + j] = (float)sr[clampi_e(col + j - 4, 0, w - 1)];
     }
     float r[32];
     exact_layers12(px, weights, w2t, r);
     if (col >= w) return;
-    float *o = planes + (long)frame * frame_pitch + (long)row * stride + col;
+    float *o = planes + (long)frame * frame_pitch + (long)(row - pl_row0) * stride + col;
 #pragma unroll
     for (int k = 0; k < 32; ++k) o[(long)k * pitch] = r[k];
 }
@@ -228,13 +230,15 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
                                                            long pitch, long frame_pitch,
                                                            uint8_t *__restrict__ dst, float *__restrict__ pre,
                                                            long dstride, long dst_frame_pitch, int w, int h,
-                                                           const float *__restrict__ kernel, float bias)
+                                                           const float *__restrict__ kernel, float bias,
+                                                           int out_row0, int out_row1, int pl_row0, int dst_row0)
 {
+    // output rows [out_row0, out_row1); planes points at map row pl_row0, dst / pre at image row dst_row0 (whole planes: 0, h, 0, 0)
     constexpr int TW = 64, TH = 4, WW = TW + 4, WH = TH + 4, WN = WW * WH;   // 68 x 8 window
     __shared__ float win[2][WN];
     // (the weights are wave-uniform: they come through the scalar cache; from LDS: 2 % slower)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col0 = blockIdx.x * TW, row0 = blockIdx.y * TH;
+    const int col0 = blockIdx.x * TW, row0 = out_row0 + blockIdx.y * TH;
     const int col = col0 + tx, row = row0 + ty;
     const int frame = blockIdx.z;
     const float *pf = planes + (long)frame * frame_pitch;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
         const int e = threadIdx.x + 256 * q;
         idx[q] = e < WN ? e : -1;
         const int wy = e / WW, wx = e % WW;
-        off[q] = (long)clampi_e(row0 + wy - 2, 0, h - 1) * stride + clampi_e(col0 + wx - 2, 0, w - 1);
+        off[q] = (long)(clampi_e(row0 + wy - 2, 0, h - 1) - pl_row0) * stride + clampi_e(col0 + wx - 2, 0, w - 1);
     }
     auto stage = [&](int ch, int buf) {
         const float *pl = pf + (long)ch * pitch;
@@ -279,9 +283,9 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
         temp = (float)((double)temp + tp);
         __syncthreads();
     }
-    if (col >= w || row >= h) return;
+    if (col >= w || row >= out_row1) return;
     temp = temp + bias;
-    const long o = (long)frame * dst_frame_pitch + (long)row * dstride + col;
+    const long o = (long)frame * dst_frame_pitch + (long)(row - dst_row0) * dstride + col;
     if (pre) pre[o] = temp;
     int q = (int)temp;                       // truncation toward zero, src/srcnn.cpp:238
     q = clampi_e(q, 0, 255);
@@ -561,11 +565,13 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     }
     __syncthreads();
     if (tid == 0) {
-        if (s_changed) { atomicAdd(&p.counters[FIX_N_CHANGED], s_changed); atomicAdd(&p.totals[FIX_N_CHANGED], s_changed); }
-        if (s_maxdev) { atomicMax(&p.counters[FIX_MAX_DEV], s_maxdev); atomicMax(&p.totals[FIX_MAX_DEV], s_maxdev); }
+        // (the context's totals are 64-bit words: at 34 k flagged pixels per 3840x2160 frame and 800 frames a second a 32-bit
+        // count wraps after two and a half minutes of streaming)
+        if (s_changed) { atomicAdd(&p.counters[FIX_N_CHANGED], s_changed); atomicAdd(&p.totals[FIX_N_CHANGED], (unsigned long long)s_changed); }
+        if (s_maxdev) { atomicMax(&p.counters[FIX_MAX_DEV], s_maxdev); atomicMax(&p.totals[FIX_MAX_DEV], (unsigned long long)s_maxdev); }
         if (blockIdx.x == 0) {
-            if (n_scat) atomicAdd(&p.totals[FIX_N_SCAT], n_scat);
-            if (n_dense) atomicAdd(&p.totals[FIX_N_DENSE], n_dense);
+            if (n_scat) atomicAdd(&p.totals[FIX_N_SCAT], (unsigned long long)n_scat);
+            if (n_dense) atomicAdd(&p.totals[FIX_N_DENSE], (unsigned long long)n_dense);
         }
     }
 }
@@ -614,7 +620,27 @@ hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_fra
 {
     // d_weights = convdata.h-order table (8,129 floats) followed by W2 transposed ([64][32]) and W1 transposed ([81][64])
     hipLaunchKernelGGL(conv99x11_exact_kernel, px_grid(w, h, n_frames), dim3(256), 0, st, src, sstride,
-                       src_frame_pitch, planes, stride, pitch, frame_pitch, w, h, d_weights, d_weights + 8129);
+                       src_frame_pitch, planes, stride, pitch, frame_pitch, w, h, d_weights, d_weights + 8129, 0, h, 0, 0);
+    return hipGetLastError();
+}
+
+// Rows [row0, row1) of ONE frame's map: src points at image row src_row0, planes at map row pl_row0.
+hipError_t launch_conv99x11_exact_rows(const uint8_t *src, long sstride, int src_row0, float *planes, long stride, long pitch,
+                                       int pl_row0, int w, int h, int row0, int row1, const float *d_weights, hipStream_t st)
+{
+    hipLaunchKernelGGL(conv99x11_exact_kernel, px_grid(w, row1 - row0, 1), dim3(256), 0, st, src, sstride, 0L, planes, stride,
+                       pitch, 0L, w, h, d_weights, d_weights + 8129, row0, row1, src_row0, pl_row0);
+    return hipGetLastError();
+}
+
+// Output rows [row0, row1) of ONE frame from map rows [row0 - 2, row1 + 2) (clamped to the image): planes points at map row
+// pl_row0, dst at image row dst_row0.
+hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, uint8_t *dst, long dstride,
+                                    int dst_row0, int w, int h, int row0, int row1, const float *d_kernel800, float bias,
+                                    hipStream_t st)
+{
+    hipLaunchKernelGGL(conv55_exact_kernel, px_grid(w, row1 - row0, 1), dim3(256), 0, st, planes, stride, pitch, 0L, dst,
+                       (float *)nullptr, dstride, 0L, w, h, d_kernel800, bias, row0, row1, pl_row0, dst_row0);
     return hipGetLastError();
 }
 
@@ -623,7 +649,7 @@ hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, lon
                                const float *d_kernel800, float bias, hipStream_t st)
 {
     hipLaunchKernelGGL(conv55_exact_kernel, px_grid(w, h, n_frames), dim3(256), 0, st, planes, stride, pitch,
-                       frame_pitch, dst, pre, dstride, dst_frame_pitch, w, h, d_kernel800, bias);
+                       frame_pitch, dst, pre, dstride, dst_frame_pitch, w, h, d_kernel800, bias, 0, h, 0, 0);
     return hipGetLastError();
 }
 

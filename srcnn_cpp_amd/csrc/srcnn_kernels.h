@@ -130,7 +130,7 @@ struct FixParams {
     int width, height, row_begin, row_end;
     const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32], then W1 transposed [81][64]
     unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel
-    unsigned *totals;               // the same four, accumulated over every launch of the context (srcnn_fixup_stats)
+    unsigned long long *totals;     // the same four as 64-bit words, accumulated over every launch of the context (srcnn_fixup_stats)
     unsigned *scat, *dense;         // work lists in FIX_REGIONS equal regions: pixel (frame * height + y) * width + x; tile index
     float delta, code_step;         // code_step = 2 delta / 253
     // one fix-up for the planes of several single-frame strip launches (srcnn_forward_y_dev): frame k of the batch lies at
@@ -188,6 +188,11 @@ hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
 hipError_t launch_seams_merged(const StripParams &p, int n_seams, const int *d_seams, const unsigned char *d_winmap, int n_frames,
                                hipStream_t stream);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
+// the same kernels with every MFMA <-> vector-ALU hazard visible to the compiler (srcnn_mfma.hip built with -DSRCNN_SAFE_HAZARDS=1)
+hipError_t launch_strip_safe(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
+// Does this device interlock the inline-asm MFMA -> packed multiply -> MFMA sequences of the fast row body?  Runs them with and
+// without wait states (srcnn_probe.hip); returns the number of results that differ (0 = interlocked), negative on a HIP error.
+long interlock_probe_mismatches(int device);
 
 size_t split16_lds_bytes();
 hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
@@ -200,6 +205,11 @@ hipError_t launch_conv11_exact(const float *planes, long stride, long pitch, flo
 hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_frame_pitch,
                                   float *planes, long stride, long pitch, long frame_pitch,
                                   int w, int h, int n_frames, const float *d_weights, hipStream_t st);
+hipError_t launch_conv99x11_exact_rows(const uint8_t *src, long sstride, int src_row0, float *planes, long stride, long pitch,
+                                       int pl_row0, int w, int h, int row0, int row1, const float *d_weights, hipStream_t st);
+hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, uint8_t *dst, long dstride,
+                                    int dst_row0, int w, int h, int row0, int row1, const float *d_kernel800, float bias,
+                                    hipStream_t st);
 hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, long frame_pitch,
                                uint8_t *dst, float *pre, long dstride, long dst_frame_pitch,
                                int w, int h, int n_frames, const float *d_kernel800, float bias,

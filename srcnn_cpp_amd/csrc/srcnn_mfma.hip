@@ -63,21 +63,31 @@
 
 #include <type_traits>
 
+// -DSRCNN_SAFE_HAZARDS=1: the FALLBACK instantiation of the strip kernels, in which every MFMA -> vector-ALU and vector-ALU -> MFMA
+// operand dependency of the row body is visible to the compiler's hazard recogniser, which then pads the wait states the ISA
+// manual asks for: the first MFMAs of the layer-2 / layer-3 chains are the builtin, ReLU is a plain max (no inline asm anywhere
+// between them).  The fast form relies on the hardware interlocking those dependencies and is ~3 % faster.  This file is
+// compiled TWICE into the library (srcnn_cpp_amd/build.py): as it is -- kernels in namespace srcnn::fast, launch_strip() and
+// the seam launchers -- and with the define -- the same strip kernels in namespace srcnn::safe behind launch_strip_safe().
+// srcnn_create() runs the row body's exact instruction sequences with and without wait states once per device
+// (srcnn_probe.hip) and the context launches the safe kernels if they ever disagree (srcnn_kernel_variant()).  Both forms
+// produce the same bytes (tests/test_gpu_hardening.py::test_safe_hazard_kernels_give_the_same_bytes).
+#ifndef SRCNN_SAFE_HAZARDS
+#define SRCNN_SAFE_HAZARDS 0
+#endif
+#if SRCNN_SAFE_HAZARDS
+#define SRCNN_KNS safe
+#else
+#define SRCNN_KNS fast
+#endif
+
 namespace srcnn {
+namespace SRCNN_KNS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// -DSRCNN_SAFE_HAZARDS: a fallback build in which every MFMA -> vector-ALU and vector-ALU -> MFMA operand dependency of the row
-// body is visible to the compiler's hazard recogniser, which then pads the wait states the ISA manual asks for: the first MFMAs
-// of the layer-2 / layer-3 chains are the builtin, ReLU is a plain max (no inline asm anywhere between them).  The product build
-// relies on the hardware interlocking those dependencies (measured: tools/mfma_interlock_probe.hip, a GPU test) and is ~3 %
-// faster; both builds must produce the same bytes (tests/test_gpu_hardening.py::test_safe_hazard_build_gives_the_same_bytes).
-#ifndef SRCNN_SAFE_HAZARDS
-#define SRCNN_SAFE_HAZARDS 0
-#endif
 
 // The first MFMA of a chain whose B operand a packed-multiply (inline asm) has just produced, written as inline asm
 // too: the compiler's hazard recogniser does not count inline-asm statements as wait states, sees the previous chain's
@@ -807,6 +817,11 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     }
 }
 
+}  // namespace SRCNN_KNS
+using namespace SRCNN_KNS;
+
+#if !SRCNN_SAFE_HAZARDS       // the seam kernels hold no MFMA: one copy, in the fast translation unit
+
 // Finishes the four output rows around every seam: replays the four chain steps the lower item's first rows
 // would have contributed to the upper item's chains (same adds in the same order as vertical() / hp_use() of
 // srcnn_strip_kernel), then the horizontal 5-term sum, bias, truncate, clamp (src/srcnn.cpp:235-240).
@@ -1003,6 +1018,15 @@ size_t strip_lds_bytes(int mode)
     // Y ring (layers 1-2) + F tiles (layer 3); Convolution55 alone needs only the tiles
     return sizeof(float) * ((mode == MODE_L3 ? 0 : 2 * YR * YP) + 2 * 3 * 6 * FW);
 }
+
+#endif  // !SRCNN_SAFE_HAZARDS
+
+#if SRCNN_SAFE_HAZARDS
+#define launch_strip launch_strip_safe
+// (LDS of a strip workgroup: the same figure as strip_lds_bytes() of the fast translation unit)
+static size_t strip_lds_bytes_safe(int mode) { return sizeof(float) * ((mode == MODE_L3 ? 0 : 2 * YR * YP) + 2 * 3 * 6 * FW); }
+#define strip_lds_bytes strip_lds_bytes_safe
+#endif
 
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad)
 {

@@ -1,6 +1,6 @@
-// san_host.cpp -- sanitizer harness for the host-only logic of srcnn_cpp_amd/csrc/srcnn_api.cpp: the work-item
+// san_host.cpp -- sanitizer harness for the host-only logic of srcnn_cpp_amd/csrc/srcnn_{api,model,plan,launch,host,multi}.cpp: the work-item
 // planner (plan_items), the MFMA / split-f16 fragment packers and the cubic coefficient tables, reached through the
-// library's own debug hooks.  tests/test_sanitizers.py compiles srcnn_api.cpp itself with
+// tuning build's debug hooks.  tests/test_sanitizers.py compiles those files themselves (-DSRCNN_TUNING_BUILD) with
 // -fsanitize=address,undefined (host compiler, no device code), links it with the kernel-launch stubs below and
 // libamdhip64, and runs this on the CPU.  No HIP call is made: nothing here needs a device.
 #include <cstdint>
@@ -19,6 +19,8 @@ hipError_t launch_seams(const StripParams &, int, const int *, hipStream_t) { re
 hipError_t launch_cseams(const StripParams &, int, hipStream_t) { return never(); }
 hipError_t launch_seams_merged(const StripParams &, int, const int *, const unsigned char *, int, hipStream_t) { return never(); }
 hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
+hipError_t launch_strip_safe(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
+long interlock_probe_mismatches(int) { return 0; }
 hipError_t launch_fixup(const FixParams &, int, hipStream_t) { return never(); }
 size_t fixup_list_entries(int, int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
@@ -26,6 +28,8 @@ hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, c
 hipError_t launch_conv11_exact(const float *, long, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv99x11_exact(const uint8_t *, long, long, float *, long, long, long, int, int, int, const float *, hipStream_t) { return never(); }
 hipError_t launch_conv55_exact(const float *, long, long, long, uint8_t *, float *, long, long, int, int, int, const float *, float, hipStream_t) { return never(); }
+hipError_t launch_conv99x11_exact_rows(const uint8_t *, long, int, float *, long, long, int, int, int, int, int, const float *, hipStream_t) { return never(); }
+hipError_t launch_conv55_exact_rows(const float *, long, long, int, uint8_t *, long, int, int, int, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_copy_rows(uint8_t *, long, const uint8_t *, long, int, int, hipStream_t) { return never(); }
 hipError_t launch_bgr2ycrcb(const uint8_t *, long, int, int, uint8_t *, long, long, hipStream_t) { return never(); }
 hipError_t launch_ycrcb2bgr(const uint8_t *, long, const uint8_t *, long, long, int, int, uint8_t *, long, hipStream_t) { return never(); }

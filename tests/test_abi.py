@@ -35,6 +35,26 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.srcnn_abi_version() == 1
 
 
+def test_product_library_has_no_debug_surface(lib):
+    """The product library reads no environment variable and exports exactly the ABI: the SRCNN_DEBUG_* experiment knobs,
+    SRCNN_HOST_COPY_THREADS and the srcnn_debug_* hooks exist only in libsrcnn_amd_tuning.so (-DSRCNN_TUNING_BUILD), and the
+    Python binding is redirected to another build only by an explicit use_library() call (no SRCNN_LIB variable)."""
+    import subprocess
+    prod, tune = S.library_path(), S.tuning_library_path()
+    assert prod.name == "libsrcnn_amd.so" and tune.exists()
+    text = prod.read_bytes()
+    for needle in (b"SRCNN_DEBUG", b"SRCNN_HOST_COPY", b"SRCNN_LIB", b"getenv"):
+        assert needle not in text, needle
+    assert b"SRCNN_DEBUG_TUNE" in tune.read_bytes()
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], check=True, capture_output=True, text=True).stdout
+        return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported(prod) == header_symbols()
+    extra = sorted(set(exported(tune)) - set(header_symbols()))
+    assert extra and all(n.startswith("srcnn_debug_") for n in extra), extra
+    assert "SRCNN_LIB" not in (ROOT / "srcnn_cpp_amd" / "__init__.py").read_text().replace("no SRCNN_LIB", "")
+
+
 def test_no_torch_or_hip_types_in_header():
     text = (ROOT / "include" / "srcnn_amd.h").read_text()
     code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -146,7 +166,7 @@ def test_exact_kernels_have_no_fused_multiply_add(tmp_path, unit):
     rounded float32 products and sums in the resize's vertical pass (HIP's __fmul_rn / __fadd_rn are plain * and +, so
     only the build flag keeps them apart).  Compiled with the flags the build uses (srcnn_cpp_amd/build.py)."""
     import subprocess
-    flags = dict(B.UNITS)[unit]
+    flags = {u[0]: u[1] for u in B.UNITS if len(u) == 2}[unit]
     assert "-ffp-contract=off" in flags
     out = tmp_path / "unit.s"
     subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, "-S",

@@ -30,10 +30,14 @@ import sys, zlib, json
 import numpy as np
 sys.path.insert(0, %r)
 import torch  # noqa: F401
+import os
 import srcnn_cpp_amd as S
 from srcnn_cpp_amd.synth import synth_luma, synth_batch
+if os.environ.get("SRCNN_TEST_TUNING_LIB"):      # the experiment knobs exist in the tuning build only
+    S.use_library(S.tuning_library_path())
 out = {}
 with S.Context(0) as ctx:
+    out["variant"] = ctx.kernel_variant()
     ctx.set_weights_blob(S.load_weights())
     for (w, h) in [(300, 70), (1920, 400), (3840, 2160)]:
         out[f"{w}x{h}"] = zlib.crc32(ctx.forward_y(synth_luma(w, h)).tobytes())
@@ -59,13 +63,15 @@ def test_debug_tune_cannot_change_pixels(weights_blob):
     for (w, h) in [(300, 70), (1920, 400), (3840, 2160)]:
         m_out, _ = oracle.gpuorder_forward_y(synth_luma(w, h), weights_blob) if w * h < 1 << 20 else (None, None)
         want[f"{w}x{h}"] = zlib.crc32(m_out.tobytes()) if m_out is not None else None
-    plain = _run_child({"SRCNN_DEBUG_TUNE": "0"})
+    plain = _run_child({"SRCNN_DEBUG_TUNE": "0", "SRCNN_TEST_TUNING_LIB": "1"})
     for key, crc in want.items():
         if crc is not None:
             assert plain[key] == crc
     for tune in ("96", "2", str(0x7FF00 | 32 | 64 | 2), "-1"):
-        got = _run_child({"SRCNN_DEBUG_TUNE": tune})
+        got = _run_child({"SRCNN_DEBUG_TUNE": tune, "SRCNN_TEST_TUNING_LIB": "1"})
         assert got == plain, f"SRCNN_DEBUG_TUNE={tune} changed the output"
+    # the PRODUCT library does not even read the variable (tests/test_abi.py checks that no such string is in the file)
+    assert _run_child({"SRCNN_DEBUG_TUNE": "96", "SRCNN_DEBUG_SEAMS": "0", "SRCNN_DEBUG_FORCE_SAFE": "1"}) == plain
 
 
 def test_half_loaded_model_is_rejected(weights_blob):
@@ -220,21 +226,32 @@ def test_reference_call_sites_with_device_planes(gpu_ctx, weights_blob):
     gpu_ctx.set_weights_blob(weights_blob)
 
 
-def test_safe_hazard_build_gives_the_same_bytes(tmp_path, weights_blob):
-    """-DSRCNN_SAFE_HAZARDS builds the strip kernels with every MFMA <-> vector-ALU dependency of the row body visible to the
-    compiler (builtin MFMAs, plain max for ReLU: the hazard recogniser pads the wait states the ISA manual asks for), as the
-    fallback should the hardware interlock the product build relies on ever not hold.  Same bytes as the product, by
-    construction of the arithmetic -- checked on planes that exercise the FAST body, the seams and a batch."""
-    env = dict(os.environ, SRCNN_BUILD_VARIANT="safe", SRCNN_BUILD_DEFINES="-DSRCNN_SAFE_HAZARDS=1")
-    subprocess.run([sys.executable, "-m", "srcnn_cpp_amd.build"], check=True, cwd=ROOT, env=env, timeout=1200,
-                   stdout=subprocess.DEVNULL)
-    lib = ROOT / "srcnn_cpp_amd" / "libsrcnn_amd_safe.so"
-    assert lib.exists()
+def test_safe_hazard_kernels_give_the_same_bytes(weights_blob):
+    """The library holds the strip kernels twice: the fast form, whose row body relies on the hardware interlocking three
+    inline-asm MFMA <-> vector-ALU dependencies, and the hazard-safe form (builtin MFMAs, plain max for ReLU: the compiler pads
+    every wait state the ISA manual asks for).  srcnn_create runs the fast form's exact sequences with and without wait states
+    on the device: here they agree (variant 0).  A context whose probe "fails" (forced through the tuning build's knob)
+    launches the safe kernels, says so, and returns the same bytes -- planes that exercise the FAST body, the seams and a
+    batch."""
     product = _run_child({})
-    safe = _run_child({"SRCNN_LIB": str(lib)})
+    assert product["variant"] == 0, "the interlock probe failed on this device"
+    safe = _run_child({"SRCNN_TEST_TUNING_LIB": "1", "SRCNN_DEBUG_FORCE_SAFE": "1"})
+    assert safe.pop("variant") == 1 and product.pop("variant") == 0
     assert safe == product
     m_out, _ = oracle.gpuorder_forward_y(synth_luma(300, 70), weights_blob)
     assert safe["300x70"] == zlib.crc32(m_out.tobytes())
+    # the same through REFBYTES (the FIX instantiations exist in both forms): the reference's bytes
+    code = ("import numpy as np, torch, srcnn_cpp_amd as S, zlib\n"
+            "from srcnn_cpp_amd.synth import synth_luma\n"
+            "S.use_library(S.tuning_library_path())\n"
+            "ctx = S.Context(0); ctx.set_weights_blob(S.load_weights()); ctx.set_mode(S.MODE_REFBYTES)\n"
+            "print(ctx.kernel_variant(), zlib.crc32(ctx.forward_y(synth_luma(1920, 400)).tobytes()), ctx._lib.srcnn_last_error(ctx._h).decode())\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
+                       env=dict(os.environ, SRCNN_DEBUG_FORCE_SAFE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    variant, crc, *msg = r.stdout.split()
+    assert variant == "1" and int(crc) == zlib.crc32(oracle.forward_y(synth_luma(1920, 400), weights_blob)[0].tobytes())
+    assert "hazard-safe" in " ".join(msg)
 
 
 def test_error_paths_of_the_round3_entry_points(weights_blob):

@@ -113,6 +113,7 @@ def test_striped_step_reports_its_halo_transport(gpu_ctx, ctx_pool):
     code = (
         "import numpy as np, torch, zlib, srcnn_cpp_amd as S\n"
         "from srcnn_cpp_amd.synth import synth_luma\n"
+        "S.use_library(S.tuning_library_path())      # the knob below exists in the tuning build only\n"
         "blob = S.load_weights(); ctxs = [S.Context(0) for _ in range(3)]\n"
         "[c.set_weights_blob(blob) for c in ctxs]\n"
         "w, h = 700, 300\n"

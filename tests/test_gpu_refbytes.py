@@ -235,3 +235,110 @@ def test_pipeline_reproduces_the_reference_picture(weights_blob, mode):
         ctx.set_mode(mode)
         out = ctx.process_bgr(fx["src_bgr"], 1.5)
     assert np.array_equal(out, fx["ref_bgr"])
+
+
+# ---- the threshold under attack, and the monitor acting ------------------------------------------------
+
+def test_adversarial_windows_keep_the_reference_bytes(ref_ctx, weights_blob):
+    """The windows an adversarial search drove to the largest |v_mfma - v_reference| (tests/checks/fixup_adversarial.py,
+    150,000 restarts on the CPU models; profiles/r04/fixup_adversarial.txt), tiled into one plane: both REFBYTES modes return
+    the reference's bytes, the monitor stays below half the threshold, and in the MFMA mode the centre pixels carry exactly
+    the value the search predicted (the CPU model it searched IS the kernel's arithmetic)."""
+    from test_adversarial import FIX, tile_windows
+    fx = np.load(FIX)
+    plane, cy, cx = tile_windows(fx["shipped_windows"])
+    r_out, _ = oracle.forward_y(plane, weights_blob)
+    assert np.array_equal(ref_ctx.forward_y(plane), r_out)
+    st = ref_ctx.fixup_stats()
+    assert 0 < st["max_dev"] < 0.5 * st["delta"], st
+    if ref_ctx.mode_under_test == S.MODE_REFBYTES:
+        with S.Context(0) as ctx:
+            ctx.set_weights_blob(weights_blob)
+            pre = np.empty(plane.shape, np.float32)
+            ctx.forward_y(plane, preclamp=pre)
+        assert np.array_equal(pre[cy, cx], fx["shipped_vals"][:, 1])
+        # the worst window found sits at 0.3 delta: the monitor sees deviations of that size when such a pixel is flagged
+        assert np.abs(pre[cy, cx] - fx["shipped_vals"][:, 0]).max() > 0.25 * st["delta"]
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_adversarial_windows_of_random_models(k):
+    from test_adversarial import FIX, tile_windows
+    fx = np.load(FIX)
+    if k >= len(fx["random_blobs"]):
+        pytest.skip("fewer models in the fixture")
+    blob = fx["random_blobs"][k]
+    plane, _, _ = tile_windows(fx["random_windows"][k])
+    r_out, _ = oracle.forward_y(plane, blob)
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(blob)
+        for mode in (S.MODE_REFBYTES, S.MODE_REFBYTES16):
+            ctx.set_mode(mode)
+            try:
+                out = ctx.forward_y(plane)
+            except S.SrcnnError as e:
+                assert mode == S.MODE_REFBYTES16 and e.code == S.ERR_STATE      # the model exceeds that mode's f16 ranges
+                continue
+            assert np.array_equal(out, r_out), mode
+            st = ctx.fixup_stats()
+            assert st["max_dev"] < 0.5 * st["delta"], (mode, st)
+
+
+def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
+    """srcnn_set_fixup_strict: with the threshold cut to its floor (srcnn_set_fixup_margin(0.25): delta = 1.5e-4, below the
+    noise) the monitor of nearly every launch exceeds delta / 2 -- strict mode notices and redoes those launches on the exact
+    kernels: the reference's bytes although the threshold no longer covers the noise, on a plane, a batch, row stripes from
+    one buffer and row stripes with their halo rows in buffers of their own.  Without strict mode the same threshold lets
+    wrong bytes through (that is what the margin is for)."""
+    import torch
+    w, h = 1000, 600
+    frames = synth_batch(w, h, 3, first_frame=2)
+    want = np.stack([oracle.forward_y(f, weights_blob)[0] for f in frames])
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        ctx.set_mode(S.MODE_REFBYTES)
+        with pytest.raises(S.SrcnnError):
+            ctx.set_fixup_margin(0.0)
+        ctx.set_fixup_margin(0.25)
+        assert ctx.fixup_stats()["delta"] < 1.6e-4
+        loose = np.stack([ctx.forward_y(f) for f in frames])
+        n_wrong = int((loose != want).sum())
+        assert ctx.fixup_stats()["exact_reruns"] == 0
+        ctx.set_fixup_strict(True)
+        assert np.array_equal(ctx.forward_y(frames[0]), want[0])
+        r1 = ctx.fixup_stats()["exact_reruns"]
+        assert r1 >= 1, "the monitor must have tripped: delta is below the measured noise"
+        assert n_wrong > 0 or r1 >= 1
+        # a device batch (one fix-up for its frames), row stripes, stripes with separate halo buffers
+        d_in = torch.from_numpy(frames).cuda()
+        d_out = torch.zeros_like(d_in)
+        torch.cuda.synchronize()
+        ctx.forward_y_dev(d_in.data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, w, h, 3)
+        ctx.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), want)
+        out = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        for k in range(3):
+            r0, r1_ = S.stripe_rows(h, 3, k)
+            s0, s1 = max(0, r0 - 6), min(h, r1_ + 6)
+            ext = d_in[1, s0:s1].contiguous()
+            torch.cuda.synchronize()
+            ctx.forward_y_rows_dev(ext.data_ptr(), w, s0, out.data_ptr(), w, 0, w, h, r0, r1_)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want[1])
+        out.zero_()
+        for k in range(3):
+            r0, r1_ = S.stripe_rows(h, 3, k)
+            own = d_in[2, r0:r1_].contiguous()
+            top = d_in[2, r0 - 6:r0].contiguous() if k > 0 else None
+            bot = d_in[2, r1_:r1_ + 6].contiguous() if k < 2 else None
+            torch.cuda.synchronize()
+            ctx.forward_y_rows_halo_dev(own.data_ptr(), w, r0, r1_ - r0, top.data_ptr() if k > 0 else 0, bot.data_ptr() if k < 2 else 0,
+                                        w, out.data_ptr(), w, 0, w, h, r0, r1_)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want[2])
+        assert ctx.fixup_stats()["exact_reruns"] > r1
+        # back at the default margin nothing trips
+        ctx.set_fixup_margin(6.0)
+        before = ctx.fixup_stats()["exact_reruns"]
+        assert np.array_equal(ctx.forward_y(frames[0]), want[0])
+        assert ctx.fixup_stats()["exact_reruns"] == before

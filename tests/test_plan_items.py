@@ -1,5 +1,6 @@
-"""CPU test of the work-item planner (plan_items() in srcnn_cpp_amd/csrc/srcnn_api.cpp) through an
-undocumented test hook of the library -- host logic only, no device needed.
+"""CPU test of the work-item planner (plan_items() in srcnn_cpp_amd/csrc/srcnn_plan.cpp) through a test hook that only the
+TUNING build of the library holds (libsrcnn_amd_tuning.so; the product exports the ABI of include/srcnn_amd.h and nothing
+else) -- host logic only, no device needed.
 
 A plane launched alone is cut into per-block work items {strip, row range, seam above, seam below}.
 Whatever heights the planner picks for speed, the items must tile every strip exactly once, in
@@ -14,10 +15,20 @@ import pytest
 import srcnn_cpp_amd as S
 
 ITEM_INTS = 5
+_tuning = None
+
+
+def tuning_lib():
+    global _tuning
+    if _tuning is None:
+        from srcnn_cpp_amd import build as B
+        B.build()
+        _tuning = C.CDLL(str(S.tuning_library_path()))
+    return _tuning
 
 
 def plan(n_cu, n_strips, r0, r1, skew=10, per_cu=2, seams=True):
-    lib = S.load_library()
+    lib = tuning_lib()
     fn = lib.srcnn_debug_plan_items
     fn.restype = C.c_int
     items = (C.c_int * (ITEM_INTS * 4096))()
@@ -125,7 +136,7 @@ def test_worker_pool_of_the_multi_gpu_entry_points():
     between calls (no thread spawn per step).  The hook runs thousands of rounds over a growing number of workers: every task
     exactly once per call, the first non-zero code returned, n - 1 threads in all.  (ASan / UBSan: tests/test_sanitizers.py.)"""
     import srcnn_cpp_amd as S
-    lib = S.load_library()
+    lib = tuning_lib()
     lib.srcnn_debug_worker_pool.restype = int
     assert lib.srcnn_debug_worker_pool(8, 3000) == 0
     assert lib.srcnn_debug_worker_pool(1, 10) == 0

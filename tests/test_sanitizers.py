@@ -1,6 +1,6 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer passes over the HOST code, CPU only -- never on
 the GPU: (1) the library's host-only logic (work-item planner, fragment packers, cubic tables) by compiling
-srcnn_api.cpp itself with the host compiler and the sanitizers; (2) the hand-written PNG / PNM decoders of
+the host units of the C-ABI layer themselves with the host compiler and the sanitizers; (2) the hand-written PNG / PNM decoders of
 tools/image_io.hpp against truncated, corrupted and crafted files (untrusted input)."""
 import shutil
 import struct
@@ -18,12 +18,13 @@ SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-f
 ENV = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1", "PATH": "/usr/bin:/bin"}
 
 pytestmark = pytest.mark.skipif(not CLANG.exists(), reason="ROCm clang++ not found")
+HOST_UNITS = [str(ROOT / "srcnn_cpp_amd" / "csrc" / f"srcnn_{u}.cpp") for u in ("api", "model", "plan", "launch", "host", "multi")]
 
 
 def test_host_logic_under_asan_ubsan(tmp_path):
     exe = tmp_path / "san_host"
-    subprocess.run([str(CLANG), *SAN, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{ROOT / 'srcnn_cpp_amd' / 'csrc'}",
-                    str(ROOT / "srcnn_cpp_amd" / "csrc" / "srcnn_api.cpp"), str(ROOT / "tests" / "checks" / "san_host.cpp"),
+    subprocess.run([str(CLANG), *SAN, "-D__HIP_PLATFORM_AMD__", "-DSRCNN_TUNING_BUILD", "-I/opt/rocm/include",
+                    f"-I{ROOT / 'srcnn_cpp_amd' / 'csrc'}", *HOST_UNITS, str(ROOT / "tests" / "checks" / "san_host.cpp"),
                     "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-pthread", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe), str(ROOT / "srcnn_cpp_amd" / "data" / "srcnn915_weights.f32")], capture_output=True,
                        text=True, env=ENV, timeout=900)
@@ -32,12 +33,12 @@ def test_host_logic_under_asan_ubsan(tmp_path):
 
 
 def test_worker_pool_under_thread_sanitizer(tmp_path):
-    """The persistent worker threads of the several-GPUs entry points (WorkerPool in srcnn_api.cpp: one mutex + condition
+    """The persistent worker threads of the several-GPUs entry points (WorkerPool in srcnn_ctx.h: one mutex + condition
     variable per worker, tasks handed over and results collected per call) under ThreadSanitizer: a data race or a lost wake-up
     in that hand-over would be a wrong row stripe once in a million steps.  The same harness, SRCNN_SAN_POOL_ONLY: only the pool."""
     exe = tmp_path / "tsan_host"
     subprocess.run([str(CLANG), "-fsanitize=thread", "-g", "-O1", "-std=c++17", "-DSRCNN_SAN_POOL_ONLY", "-D__HIP_PLATFORM_AMD__",
-                    "-I/opt/rocm/include", f"-I{ROOT / 'srcnn_cpp_amd' / 'csrc'}", str(ROOT / "srcnn_cpp_amd" / "csrc" / "srcnn_api.cpp"),
+                    "-DSRCNN_TUNING_BUILD", "-I/opt/rocm/include", f"-I{ROOT / 'srcnn_cpp_amd' / 'csrc'}", *HOST_UNITS,
                     str(ROOT / "tests" / "checks" / "san_host.cpp"), "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib",
                     "-pthread", "-o", str(exe)], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True, env={"PATH": "/usr/bin:/bin", "TSAN_OPTIONS": "halt_on_error=1"},

@@ -7,5 +7,5 @@ REPS=${REPS:-3}
 kms() { python bench.py --no-cpu-baseline --no-e2e --no-refbytes "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['output_crc32'][0])"; }
 for i in $(seq $REPS); do
   echo -n "product: "; kms --steps 50 "$@"
-  echo -n "$V: "; SRCNN_LIB=$(pwd)/srcnn_cpp_amd/libsrcnn_amd_$V.so kms --steps 50 "$@"
+  echo -n "$V: "; kms --lib $(pwd)/srcnn_cpp_amd/libsrcnn_amd_$V.so --steps 50 "$@"
 done

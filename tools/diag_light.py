@@ -8,6 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.environ["SRCNN_DEBUG_TUNE"] = "16"
 import numpy as np, torch
 import srcnn_cpp_amd as S
+S.use_library(S.tuning_library_path())      # the stamped kernels and srcnn_debug_read_sink live in the tuning build
 from srcnn_cpp_amd.synth import synth_batch
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)

@@ -6,6 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.environ["SRCNN_DEBUG_TUNE"] = os.environ.get("SRCNN_DEBUG_TUNE", "2")
 import numpy as np, torch
 import srcnn_cpp_amd as S
+S.use_library(S.tuning_library_path())      # the stamped kernels and srcnn_debug_read_sink live in the tuning build
 from srcnn_cpp_amd.synth import synth_batch
 W, H = 3840, 2160
 ctx = S.Context(0); ctx.set_weights_blob(S.load_weights()); ctx.set_mode(S.MODE_SPLIT16)
