@@ -76,8 +76,7 @@ __global__ __launch_bounds__(256) void conv11_exact_kernel(const float *__restri
 // then sums its inputs in ascending channel order (src/srcnn.cpp:312-315) -- same products, same order, same roundings as
 // the reference.  Weights are wave-uniform and come through the scalar cache: weights = b1[64] | W1[64][81] | b2[32] |
 // W2[32][64] | b3 | W3 (convdata.h order, 8,129 floats), then W2 transposed to [64][32] and W1 transposed to [81][64], so that
-// what one step of either loop needs is contiguous.  exact_layers12_lds() is shared by the whole-plane kernel below and by
-// the fix-up kernel of SRCNN_MODE_REFBYTES.
+// what one step of either loop needs is contiguous (+ one tap of zeros behind it: the fix-up kernel fetches a tap ahead).
 // The weight tables are read through the CONSTANT address space: wave-uniform addresses there become scalar loads (s_load,
 // through the scalar cache, no vector-memory latency in the channel loop) whatever else the kernel stores to global memory --
 // for a plain global pointer the compiler keeps scalar loads only while it can prove no store of the kernel may alias them,
@@ -86,73 +85,108 @@ typedef const __attribute__((address_space(4))) float *cfloat_p;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cfloat_p as_constant(const float *p) { return (cfloat_p)p; }
 
-// Layers 1-2 of ONE feature position per lane, the luma window read from LDS: ywin[row_of(i) + cofs[j]] is the (already
-// border-replicated) value under tap (i, j).  Tap-outer: the 64 layer-1 sums of the position advance together, one luma value
-// against the 64 weights of its tap (W1 transposed [81][64] at wraw + 10177) -- per channel the same rounded products added in
-// the same order as the reference's loop (src/srcnn.cpp:283-305), but 64 independent chains instead of one dependent chain per
-// channel, two channels per packed instruction (v_pk_mul_f32 / v_pk_add_f32 with the weights as an SGPR pair:
-// profiles/r03/pk_f32_probe.txt), and no 81-register window.  The 64 weights of a tap are fetched as four 16-float scalar
-// loads issued TOGETHER: scalar loads return out of order, so every wait is lgkmcnt(0), and left to itself the compiler issues
-// one load right before its use -- the wave then stalls for the scalar cache's latency 452 times per position (fix_apply_kernel
-// 334 us per 3840x2160 plane in that form, 250 in this one; a half-tap software pipeline on top: no further gain; the
-// same grouping in layer 2: 3 % slower).  Layer 2: r[k] = r[k] + a_i * W2[k][i], i ascending (:307-317), 32 independent chains.
+// The fix-up kernel's layers 1-2 (exact_layer1_half / exact_layer2_half below) read the luma window from LDS --
+// ywin[row_of(i) + cofs[j]] is the (already border-replicated) value under tap (i, j) -- and run TAP-OUTER: the layer-1 sums of a
+// position advance together, one luma value against the weights of its tap (W1 transposed [81][64] at wraw + 10177) -- per
+// channel the same rounded products added in the same order as the reference's loop (src/srcnn.cpp:283-305), but independent
+// chains instead of one dependent chain per channel, two channels per packed instruction (v_pk_mul_f32 / v_pk_add_f32 with the
+// weights as an SGPR pair: profiles/r03/pk_f32_probe.txt), and no 81-register window.  History of that loop, same-box steps on a
+// 3840x2160 plane: register-window form 328 us -> tap-outer, one scalar load at a time 334 -> a tap's four loads issued together
+// 252 (round 3) -> two lanes per position, loads one tap ahead, layer 2 packed too: 232 (profiles/r04/fix_apply_ab.txt).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef const __attribute__((address_space(4))) f32x16 *cvec16_p;
+// (the tables these loads read are only DWORD aligned -- W1 transposed starts at float 10177 of the table, a layer-3 channel
+// every 25 floats: the pointee types say so, an s_load_dwordx16 / x8 needs no more)
+typedef f32x16 f32x16_a4 __attribute__((aligned(4)));
+typedef const __attribute__((address_space(4))) f32x16_a4 *cvec16_p;
 
+// The same arithmetic for HALF a feature position: the 32 layer-1 channels [32 hh, 32 hh + 32) of the lane's position (hh is
+// wave-uniform: the weights stay scalar operands), then the lane's share of every layer-2 chain -- input channels
+// [32 hh, 32 hh + 32) folded, in ascending order, into the 32 running sums r[], which for hh = 1 arrive holding the hh = 0
+// lane's result.  Two lanes per position halve the time one work item of fix_apply_kernel takes; every chain keeps the
+// reference's order (src/srcnn.cpp:288-317).
+// Scalar loads return out of order, so the only wait for one is lgkmcnt(0) -- which also waits for every load issued since.
+// A tap's weights are therefore fetched ONE TAP AHEAD and the wait is pinned (an empty asm that reads the registers) in front of
+// the next fetch: [wait for tap t] [fetch tap t + 1] [32 packed operations of tap t] -- the fetch has the whole tap to arrive.
+// With 64 channels per lane that needs 128 scalar registers; with 32 it fits.  The luma values of a window row are read from
+// LDS one ROW ahead for the same reason (LDS reads share the counter).
 template <class RowOf>
-__device__ __forceinline__ void exact_layers12_lds(const float *ywin, RowOf row_of, const int (&cofs)[9], const float *wraw,
-                                                   float (&r)[32])
+__device__ __forceinline__ void exact_layer1_half(const float *ywin, RowOf row_of, const int (&cofs)[9], const float *wraw, int hh,
+                                                  f32x2 (&acc)[16])
 {
     const cfloat_p wr = as_constant(wraw);
-    const cfloat_p b1 = wr, b2 = wr + 5248, w2t = wr + 8129, w1t = wr + 10177;
-    f32x2 acc[32];
+    const cfloat_p b1 = wr + 32 * hh;
+    cvec16_p wrow = (cvec16_p)(wr + 10177 + 32 * hh);     // tap t at wrow[4 t], [4 t + 1]; the table is padded by one tap (upload_weights)
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = f32x2{0.f, 0.f};
+    for (int c = 0; c < 16; ++c) acc[c] = f32x2{0.f, 0.f};
+    float ycur[9], ynext[9];
+    {
+        const int ro = row_of(0);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ycur[j] = ywin[ro + cofs[j]];
+    }
+    f32x16 w0c = wrow[0], w1c = wrow[1];
 #pragma unroll 1
     for (int i = 0; i < 9; ++i) {
-        const int ro = row_of(i);
-        const cvec16_p wrow = (cvec16_p)(w1t + i * 9 * 64);
+        const int ro_n = row_of(i < 8 ? i + 1 : 8);
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            const float yv = ywin[ro + cofs[j]];
-            const f32x2 yy = {yv, yv};
-            const f32x16 w0 = wrow[4 * j], w1 = wrow[4 * j + 1], w2 = wrow[4 * j + 2], w3 = wrow[4 * j + 3];
+            asm volatile("" ::"s"(w0c), "s"(w1c));                             // tap (i, j)'s weights have arrived
+            const f32x16 w0n = wrow[4 * (j + 1)], w1n = wrow[4 * (j + 1) + 1];   // tap (i, j + 1), or (i + 1, 0): rows are contiguous
+            if (j == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 9; ++jj) ynext[jj] = ywin[ro_n + cofs[jj]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x2 yy = {ycur[j], ycur[j]};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const f32x2 a0 = {w0[2 * c], w0[2 * c + 1]}, a1 = {w1[2 * c], w1[2 * c + 1]};
-                const f32x2 a2 = {w2[2 * c], w2[2 * c + 1]}, a3 = {w3[2 * c], w3[2 * c + 1]};
-                const f32x2 p0 = a0 * yy, p1 = a1 * yy, p2 = a2 * yy, p3 = a3 * yy;
+                const f32x2 a0 = {w0c[2 * c], w0c[2 * c + 1]}, a1 = {w1c[2 * c], w1c[2 * c + 1]};
+                const f32x2 p0 = a0 * yy, p1 = a1 * yy;
                 acc[c] = acc[c] + p0;
                 acc[8 + c] = acc[8 + c] + p1;
-                acc[16 + c] = acc[16 + c] + p2;
-                acc[24 + c] = acc[24 + c] + p3;
             }
+            __builtin_amdgcn_sched_barrier(0);
+            w0c = w0n;
+            w1c = w1n;
         }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ycur[j] = ynext[j];
+        wrow += 4 * 9;
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
+    for (int c = 0; c < 16; ++c) {
         const f32x2 bv = {b1[2 * c], b1[2 * c + 1]};
         f32x2 a = acc[c] + bv;
         a.x = (a.x < 0) ? 0.f : a.x;
         a.y = (a.y < 0) ? 0.f : a.y;
         acc[c] = a;
     }
+}
+// layer 2, this lane's 32 input channels: the next channel's 32 weights are fetched while the current one's products run
+__device__ __forceinline__ void exact_layer2_half(const f32x2 (&acc)[16], const float *wraw, int hh, f32x2 (&r)[16])
+{
+    const cvec16_p w2t = (cvec16_p)(as_constant(wraw) + 8129 + 32 * hh * 32);      // input channel i at w2t[2 i], [2 i + 1]
+    f32x16 w0c = w2t[0], w1c = w2t[1];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) r[k] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < 32; ++i) {
+        asm volatile("" ::"s"(w0c), "s"(w1c));
+        // (the fetch behind the last channel of hh = 1 reads the first tap of the W1T table that follows: in bounds)
+        const f32x16 w0n = w2t[2 * (i + 1)], w1n = w2t[2 * (i + 1) + 1];
+        __builtin_amdgcn_sched_barrier(0);
         const float ai = (i & 1) ? acc[i >> 1].y : acc[i >> 1].x;
-        const cfloat_p w2i = w2t + i * 32;
+        const f32x2 aa = {ai, ai};
+        // two output channels per packed instruction, the weights as a scalar-register pair (the rounded product and the
+        // rounded add of either half are what the plain instructions give)
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float pr = ai * w2i[k];
-            r[k] = r[k] + pr;
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 wa = {w0c[2 * k], w0c[2 * k + 1]}, wb = {w1c[2 * k], w1c[2 * k + 1]};
+            const f32x2 p0 = wa * aa, p1 = wb * aa;
+            r[k] = r[k] + p0;
+            r[8 + k] = r[8 + k] + p1;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        const float v = r[k] + b2[k];
-        r[k] = (v < 0) ? 0.f : v;
+        __builtin_amdgcn_sched_barrier(0);
+        w0c = w0n;
+        w1c = w1n;
     }
 }
 
@@ -265,11 +299,12 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
         if (i + 1 < 32) stage(i + 1, (i + 1) & 1);
         const float *wv = &win[i & 1][ty * WW + tx];
         double tp = 0.0;
-        // the channel's 25 weights as three scalar loads issued together (see exact_layers12_lds): 893 -> 878 us per 3840x2160 plane
+        // the channel's 25 weights as three scalar loads issued together (see exact_layer1_half): 893 -> 878 us per 3840x2160 plane
         typedef float f32x8 __attribute__((ext_vector_type(8)));
+        typedef f32x8 f32x8_a4 __attribute__((aligned(4)));
         const cfloat_p kc = as_constant(kernel) + i * 25;
         const f32x16 wa = *(cvec16_p)kc;
-        const f32x8 wb = *(const __attribute__((address_space(4))) f32x8 *)(kc + 16);
+        const f32x8 wb = *(const __attribute__((address_space(4))) f32x8_a4 *)(kc + 16);
         const float wc = kc[24];
 #pragma unroll
         for (int m = 0; m < 5; ++m)
@@ -308,8 +343,12 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
 // Result: the reference's byte in every pixel whose |v_mfma - v_ref| <= delta -- all of them, on every input tried
 // (tests/test_gpu_refbytes.py; fix_apply also records the largest |v_mfma - v_ref| it sees over the flagged pixels, a
 // ~0.4 % random sample of the plane, so a caller can watch the margin: srcnn_fixup_stats()).
-constexpr int FIX_TILE = 12, FIX_POS = FIX_TILE + 4, FIX_GROUP = 10, FIX_DENSE_MIN = 11;
-static_assert(FIX_POS * FIX_POS == 256 && FIX_GROUP * 25 <= 256, "one feature position per lane");
+// TWO lanes per feature position (each 32 of the 64 layer-1 channels, then its half of every layer-2 chain): an item is 5
+// scattered pixels = 125 positions, or a third of a dense tile's window = 8 x 16 positions = 4 x 12 output pixels.  A dense tile
+// costs 3 x 128 positions, as much as 15 scattered pixels.
+constexpr int FIX_TILE = 12, FIX_POS = FIX_TILE + 4, FIX_GROUP = 5, FIX_DENSE_MIN = 16;
+constexpr int FIX_HALF = 128, FIX_SUB_ROWS = 4;         // positions per item; output rows per dense sub-pass
+static_assert(FIX_GROUP * 25 <= FIX_HALF && (FIX_SUB_ROWS + 4) * FIX_POS == FIX_HALF && FIX_TILE % FIX_SUB_ROWS == 0, "two lanes per position");
 
 // non-zero bytes of a dword, as a count
 __device__ __forceinline__ int nz_bytes(unsigned dw)
@@ -393,20 +432,32 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
     for (unsigned i = tid; i < s_ndense; i += 256) p.dense[s_base_dense + i] = s_dense[i];
 }
 
-// Items [0, n_dense) are dense tiles, items [n_dense, n_dense + ceil(n_scat / 10)) groups of 10 scattered pixels.  The grid is
-// what the GPU holds at once (4 workgroups per CU: 128 VGPRs, 39 KB of LDS); workgroups draw items from a shared counter until none is left
-// (an item is ~40 us of work, a draw ~1 us).  Lane t of an item computes layers 1-2 of ONE feature position: position (t / 16, t % 16)
-// of the tile's 16 x 16 window (tile origin - 2), or tap t % 25 of scattered pixel t / 25.
-__global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
+// Items [0, n_dense) are dense tiles, items [n_dense, n_dense + ceil(n_scat / FIX_GROUP)) groups of FIX_GROUP scattered pixels.
+// The grid is what the GPU holds at once; workgroups draw items from a shared counter until none is left.
+//
+// TWO LANES PER FEATURE POSITION.  Lane t works on position q = t & 127 -- tap q % 25 of scattered pixel q / 25, or position
+// (q / 16, q % 16) of a dense sub-window -- with hh = t >> 7 (wave-uniform, so the weights stay scalar operands): it computes the
+// layer-1 channels [32 hh, 32 hh + 32) of the position (exact_layer1_half) and folds them into the 32 layer-2 chains
+// (exact_layer2_half).  A layer-2 sum is ONE chain over the 64 input channels in ascending order (src/srcnn.cpp:312-315), so the
+// hh = 1 lane continues where the hh = 0 lane of its position stopped: the 32 running sums cross through LDS, one barrier
+// between the two halves of layer 2 (other workgroups of the CU fill the wait).  Round 3 ran one lane per position, 250 per
+// item: an item took ~62 us, 3,390 of them over 1,024 resident workgroups = 3.3 rounds, the last one two thirds empty, and on a
+// 1920x1080 plane the whole fix-up was ONE item's latency.  Now an item is half as long (5 scattered pixels), the last round
+// costs half as much, and the registers a lane no longer needs (32 channel sums instead of 64) buy a fifth workgroup per CU.
+// A dense tile's 16 x 16 window goes through in three sub-windows of 8 x 16 positions (rows 0-7, 4-11, 8-15 -> output rows
+// 0-3, 4-7, 8-11): 1.5 x the positions of round 3's one pass, on the rare flat / periodic content only.
+__global__ __launch_bounds__(256, 5) void fix_apply_kernel(const FixParams p)
 {
-    __shared__ float Fs[256][33];           // layer-2 activations per position (pitch 33: conflict-free both ways)
+    __shared__ float Fs[FIX_HALF][33];      // per position: the layer-2 chains between the two halves, then the activations
+    __shared__ float s_y[FIX_GROUP * 169 > 16 * 24 ? FIX_GROUP * 169 : 16 * 24];   // the luma the item's positions read
     __shared__ double s_tp[FIX_GROUP][32];  // scattered items: the 25-term double sums per (pixel, channel)
     __shared__ float s_w3[800];
     __shared__ unsigned s_changed, s_maxdev, s_item;
     const int tid = threadIdx.x;
+    const int q = tid & (FIX_HALF - 1);
+    const int hh = __builtin_amdgcn_readfirstlane(tid >> 7);
     for (int i = tid; i < 800; i += 256) s_w3[i] = p.wraw[7329 + i];
     if (tid == 0) { s_changed = 0; s_maxdev = 0; }
-    // items: the dense tiles of regions 0 .. 7, then the groups of FIX_GROUP scattered pixels of regions 0 .. 7
     unsigned nd[FIX_REGIONS], ns[FIX_REGIONS], n_dense = 0, n_scat = 0, n_groups = 0;
 #pragma unroll
     for (int r = 0; r < FIX_REGIONS; ++r) {
@@ -422,8 +473,11 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
     const int W = p.width, H = p.height;
     const int tiles_x = (W + FIX_TILE - 1) / FIX_TILE, bands = (p.row_end - p.row_begin + FIX_TILE - 1) / FIX_TILE;
     const float b3 = p.wraw[7328];
+    const cfloat_p b2 = as_constant(p.wraw) + 5248;
+    // (rows beyond row_end + 5 feed no pixel of this launch: a row stripe's caller provides [row_begin - 6, row_end + 6))
+    const int y_hi = min(H - 1, p.row_end + 5);
     // The first item of a workgroup is its own index, the later ones are drawn from the shared counter (which therefore counts
-    // from gridDim.x): 1,024 workgroups drawing at once would queue on the one word for 12 us (~88 returning atomics per us).
+    // from gridDim.x): every resident workgroup drawing at once would queue on the one word (~88 returning atomics per us).
     for (bool first_round = true;; first_round = false) {
         __syncthreads();                         // s_item's readers of the previous round are done (and the kernel's LDS set-up)
         if (tid == 0) s_item = first_round ? blockIdx.x : gridDim.x + atomicAdd(&p.counters[FIX_NEXT_ITEM], 1u);
@@ -431,20 +485,6 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
         const unsigned item = s_item;
         if (item >= n_items) break;
         const bool dense = item < n_dense;       // uniform
-        // The luma the item's positions read is staged ONCE in LDS, as floats, addressed by image coordinate relative to the
-        // window's origin (a lane gathering its 81 bytes from global memory costs 81 uncoalesced vector loads: 20,736 lane
-        // addresses per item through the CU's one texture path against ~1,700 here).  Scattered pixel o: the 13 x 13 image
-        // window around it at ywin[o * 169]; dense tile: the 24 x 24 window around the tile.  Elements outside the image (or
-        // beyond the rows a stripe's caller provides) are never read: every read address is a CLAMPED coordinate.  The buffer
-        // aliases Fs, which is written only after every lane has finished layers 1-2 (barrier below).
-        float *ywin = &Fs[0][0];
-        int py, px_;                             // this lane's feature position (clamped image coordinates)
-        int wy0, wx0, wbase, wpitch;             // origin (image coordinates), LDS base and pitch of the window this lane reads
-        bool active;
-        int ty0 = 0, tx0 = 0, frame = 0;
-        unsigned first = 0;
-        // (rows beyond row_end + 5 feed no pixel of this launch: a row stripe's caller provides [row_begin - 6, row_end + 6))
-        const int y_hi = min(H - 1, p.row_end + 5);
         // the item's region and its index there (uniform)
         unsigned idx = dense ? item : item - n_dense, reg = 0;
 #pragma unroll
@@ -456,80 +496,109 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
 #pragma unroll
         for (int r = 1; r < FIX_REGIONS; ++r) n_reg = reg == (unsigned)r ? ns[r] : n_reg;
         const unsigned *scat = p.scat + reg * scat_cap;
+        int ty0 = 0, tx0 = 0, frame = 0;
+        unsigned first = 0;
         if (dense) {
             const unsigned t = p.dense[reg * dense_cap + idx];
             const unsigned trow = t / (unsigned)tiles_x;                 // frame * bands + band
             frame = (int)(trow / (unsigned)bands);
             ty0 = p.row_begin + (int)(trow % (unsigned)bands) * FIX_TILE;
             tx0 = (int)(t % (unsigned)tiles_x) * FIX_TILE;
-            py = clampi_e(ty0 - 2 + tid / FIX_POS, 0, min(H - 1, p.row_end + 1));     // (positions below row_end + 1 feed no pixel)
-            px_ = clampi_e(tx0 - 2 + tid % FIX_POS, 0, W - 1);
-            wy0 = ty0 - 6; wx0 = tx0 - 6; wbase = 0; wpitch = FIX_POS + 8;
-            for (int e = tid; e < (FIX_POS + 8) * (FIX_POS + 8); e += 256) {
-                const int yy = wy0 + e / (FIX_POS + 8), xx = wx0 + e % (FIX_POS + 8);
-                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
-                    ywin[e] = (float)fix_src_at(p, frame, yy, xx);
-            }
         } else {
             first = idx * FIX_GROUP;
-            const unsigned o = (unsigned)tid / 25u, tap = (unsigned)tid % 25u;
-            active = tid < FIX_GROUP * 25 && first + o < n_reg;
-            // (idle lanes recompute the group's first pixel: any other coordinates could lie outside a row stripe's input)
-            const unsigned oo = active ? o : 0u;
-            const unsigned pix = scat[first + oo];
-            const int y = (int)((pix / (unsigned)W) % (unsigned)H), x = (int)(pix % (unsigned)W);
-            py = clampi_e(y + (int)(tap / 5u) - 2, 0, H - 1);     // the layer-3 border replicates FEATURE coordinates (:196-210)
-            px_ = clampi_e(x + (int)(tap % 5u) - 2, 0, W - 1);
-            wy0 = y - 6; wx0 = x - 6; wbase = (int)oo * 169; wpitch = 13;
-            const unsigned n_here = min((unsigned)FIX_GROUP, n_reg - first);
-            for (unsigned e = tid; e < n_here * 169u; e += 256) {
-                const unsigned q = e / 169u, k = e % 169u;
-                const unsigned pq = scat[first + q];
-                const unsigned fy = pq / (unsigned)W;                       // frame * H + y
-                const int fq = (int)(fy / (unsigned)H);
-                const int yy = (int)(fy % (unsigned)H) - 6 + (int)(k / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(k % 13u);
-                if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W)
-                    ywin[e] = (float)fix_src_at(p, fq, yy, xx);
-            }
         }
-        __syncthreads();
-        // ---- layers 1-2 of this lane's position ----
-        float r[32];
-        {
-            int cofs[9];
-#pragma unroll
-            for (int j = 0; j < 9; ++j) cofs[j] = wbase + clampi_e(px_ + j - 4, 0, W - 1) - wx0;
-            exact_layers12_lds(ywin, [&](int i) { return (clampi_e(py + i - 4, 0, H - 1) - wy0) * wpitch; }, cofs, p.wraw, r);
-        }
-        __syncthreads();                          // every lane is done with the luma window, the previous item's readers with Fs (same LDS)
-#pragma unroll
-        for (int k = 0; k < 32; ++k) Fs[tid][k] = r[k];
-        __syncthreads();
-        // ---- layer 3 ----
-        if (dense) {
-            const int ly = tid / FIX_TILE, lx = tid % FIX_TILE;       // threads 0..143: one output pixel each
-            const int y = ty0 + ly, x = tx0 + lx;
-            if (tid < FIX_TILE * FIX_TILE && y < p.row_end && x < W) {
-                float temp = 0.f;
-                for (int c = 0; c < 32; ++c) {
-                    double tp = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 5; ++m)
-#pragma unroll
-                        for (int n = 0; n < 5; ++n) {
-                            const float pr = s_w3[(c * 5 + m) * 5 + n] * Fs[(ly + m) * FIX_POS + lx + n][c];
-                            tp = tp + (double)pr;
-                        }
-                    temp = (float)((double)temp + tp);
+        const int n_sub = dense ? FIX_TILE / FIX_SUB_ROWS : 1;
+        for (int sub = 0; sub < n_sub; ++sub) {
+            if (sub) __syncthreads();            // the previous sub-window's layer 3 is done with Fs
+            // The luma the positions read is staged ONCE in LDS, as floats, addressed by image coordinate relative to the window's
+            // origin.  Scattered pixel o: the 13 x 13 image window around it at s_y[o * 169]; dense sub-window: the 16 x 24 window
+            // around its 8 x 16 positions.  Elements outside the image (or beyond the rows a stripe's caller provides) are never
+            // read: every read address is a CLAMPED coordinate.
+            int py, px_, wy0, wx0, wbase, wpitch;
+            const int sy0 = ty0 + sub * FIX_SUB_ROWS;                    // first output row of the sub-window
+            if (dense) {
+                if (sy0 >= p.row_end) break;                             // (uniform) the band's last tiles may be cut by row_end
+                py = clampi_e(sy0 - 2 + q / FIX_POS, 0, min(H - 1, p.row_end + 1));     // (positions below row_end + 1 feed no pixel)
+                px_ = clampi_e(tx0 - 2 + q % FIX_POS, 0, W - 1);
+                wy0 = sy0 - 6; wx0 = tx0 - 6; wbase = 0; wpitch = FIX_POS + 8;
+                for (int e = tid; e < (FIX_SUB_ROWS + 12) * (FIX_POS + 8); e += 256) {
+                    const int yy = wy0 + e / (FIX_POS + 8), xx = wx0 + e % (FIX_POS + 8);
+                    if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W) s_y[e] = (float)fix_src_at(p, frame, yy, xx);
                 }
-                temp = temp + b3;
-                const uint8_t q = (uint8_t)clampi_e((int)temp, 0, 255);
-                uint8_t *d = p.dst + (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + x;
-                if (*d != q) { *d = q; atomicAdd(&s_changed, 1u); }
+            } else {
+                const unsigned o = (unsigned)q / 25u, tap = (unsigned)q % 25u;
+                const bool active = q < FIX_GROUP * 25 && first + o < n_reg;
+                // (idle lanes recompute the group's first pixel: any other coordinates could lie outside a row stripe's input)
+                const unsigned oo = active ? o : 0u;
+                const unsigned pix = scat[first + oo];
+                const int y = (int)((pix / (unsigned)W) % (unsigned)H), x = (int)(pix % (unsigned)W);
+                py = clampi_e(y + (int)((active ? tap : 0u) / 5u) - 2, 0, H - 1);     // the layer-3 border replicates FEATURE coordinates (:196-210)
+                px_ = clampi_e(x + (int)((active ? tap : 0u) % 5u) - 2, 0, W - 1);
+                wy0 = y - 6; wx0 = x - 6; wbase = (int)oo * 169; wpitch = 13;
+                const unsigned n_here = min((unsigned)FIX_GROUP, n_reg - first);
+                for (unsigned e = tid; e < n_here * 169u; e += 256) {
+                    const unsigned k = e / 169u, m = e % 169u;
+                    const unsigned pq = scat[first + k];
+                    const unsigned fy = pq / (unsigned)W;                       // frame * H + y
+                    const int fq = (int)(fy / (unsigned)H);
+                    const int yy = (int)(fy % (unsigned)H) - 6 + (int)(m / 13u), xx = (int)(pq % (unsigned)W) - 6 + (int)(m % 13u);
+                    if (yy >= 0 && yy <= y_hi && xx >= 0 && xx < W) s_y[e] = (float)fix_src_at(p, fq, yy, xx);
+                }
             }
-        } else {
-            for (int round = 0; round < (FIX_GROUP + 7) / 8; ++round) {
-                const int o = tid / 32 + 8 * round, c = tid % 32;
+            __syncthreads();
+            // ---- layer 1 (this lane's 32 channels), layer 2 in two halves ----
+            f32x2 acc[16];
+            {
+                int cofs[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) cofs[j] = wbase + clampi_e(px_ + j - 4, 0, W - 1) - wx0;
+                exact_layer1_half(s_y, [&](int i) { return (clampi_e(py + i - 4, 0, H - 1) - wy0) * wpitch; }, cofs, p.wraw, hh, acc);
+            }
+            f32x2 r[16];
+            if (hh == 0) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r[k] = f32x2{0.f, 0.f};
+                exact_layer2_half(acc, p.wraw, 0, r);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = r[k].x; Fs[q][2 * k + 1] = r[k].y; }
+            }
+            __syncthreads();                     // (also: the previous item's layer 3 finished with Fs before the first barrier of this one)
+            if (hh == 1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) r[k] = f32x2{Fs[q][2 * k], Fs[q][2 * k + 1]};
+                exact_layer2_half(acc, p.wraw, 1, r);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float v0 = r[k].x + b2[2 * k], v1 = r[k].y + b2[2 * k + 1];
+                    Fs[q][2 * k] = (v0 < 0) ? 0.f : v0;
+                    Fs[q][2 * k + 1] = (v1 < 0) ? 0.f : v1;
+                }
+            }
+            __syncthreads();
+            // ---- layer 3 ----
+            if (dense) {
+                const int ly = tid / FIX_TILE, lx = tid % FIX_TILE;       // threads 0..47: one output pixel each
+                const int y = sy0 + ly, x = tx0 + lx;
+                if (tid < FIX_SUB_ROWS * FIX_TILE && y < p.row_end && x < W) {
+                    float temp = 0.f;
+                    for (int c = 0; c < 32; ++c) {
+                        double tp = 0.0;
+#pragma unroll
+                        for (int m = 0; m < 5; ++m)
+#pragma unroll
+                            for (int n = 0; n < 5; ++n) {
+                                const float pr = s_w3[(c * 5 + m) * 5 + n] * Fs[(ly + m) * FIX_POS + lx + n][c];
+                                tp = tp + (double)pr;
+                            }
+                        temp = (float)((double)temp + tp);
+                    }
+                    temp = temp + b3;
+                    const uint8_t qv = (uint8_t)clampi_e((int)temp, 0, 255);
+                    uint8_t *d = p.dst + (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + x;
+                    if (*d != qv) { *d = qv; atomicAdd(&s_changed, 1u); }
+                }
+            } else {
+                const int o = tid / 32, c = tid % 32;                      // threads 0..159: one (pixel, channel) each
                 if (o < FIX_GROUP && first + o < n_reg) {
                     double tp = 0.0;
 #pragma unroll
@@ -539,27 +608,27 @@ __global__ __launch_bounds__(256, 4) void fix_apply_kernel(const FixParams p)
                     }
                     s_tp[o][c] = tp;
                 }
-            }
-            __syncthreads();
-            if (tid < FIX_GROUP && first + tid < n_reg) {
-                float temp = 0.f;
-                for (int c = 0; c < 32; ++c) temp = (float)((double)temp + s_tp[tid][c]);
-                temp = temp + b3;
-                const uint8_t q = (uint8_t)clampi_e((int)temp, 0, 255);
-                const unsigned pix = scat[first + tid];
-                const unsigned fy = pix / (unsigned)W;
-                const long oin = (long)((int)(fy % (unsigned)H) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
-                const long o = (long)(fy / (unsigned)H) * p.dst_frame_pitch + oin;
-                const long of = (long)(fy / (unsigned)H) * p.flag_frame_pitch + oin;
-                // how far the MFMA path's value was from the reference's: v_mfma = rint(v) + (code's distance), rint(v) = the
-                // stored byte (+ 1 where v sat just below the integer).  The code resolves the distance to delta / 253, so a v
-                // AT an integer can decode to the other side of it: the difference is therefore taken modulo 1 (both
-                // values lie within delta << 0.5 of the same integer)
-                const float dist = ((float)p.flag[of] - 1.f) * p.code_step - p.delta;
-                const float v_mfma = (float)p.dst[o] + (dist < 0.f ? 1.f : 0.f) + dist;
-                const float dev = v_mfma - temp;
-                atomicMax(&s_maxdev, __float_as_uint(fabsf(dev - rintf(dev))));
-                if (p.dst[o] != q) { p.dst[o] = q; atomicAdd(&s_changed, 1u); }
+                __syncthreads();
+                if (tid < FIX_GROUP && first + tid < n_reg) {
+                    float temp = 0.f;
+                    for (int c2 = 0; c2 < 32; ++c2) temp = (float)((double)temp + s_tp[tid][c2]);
+                    temp = temp + b3;
+                    const uint8_t qv = (uint8_t)clampi_e((int)temp, 0, 255);
+                    const unsigned pix = scat[first + tid];
+                    const unsigned fy = pix / (unsigned)W;
+                    const long oin = (long)((int)(fy % (unsigned)H) - p.dst_row0) * p.dst_stride + (int)(pix % (unsigned)W);
+                    const long o2 = (long)(fy / (unsigned)H) * p.dst_frame_pitch + oin;
+                    const long of = (long)(fy / (unsigned)H) * p.flag_frame_pitch + oin;
+                    // how far the MFMA path's value was from the reference's: v_mfma = rint(v) + (code's distance), rint(v) = the
+                    // stored byte (+ 1 where v sat just below the integer).  The code resolves the distance to delta / 253, so a v
+                    // AT an integer can decode to the other side of it: the difference is therefore taken modulo 1 (both
+                    // values lie within delta << 0.5 of the same integer)
+                    const float dist = ((float)p.flag[of] - 1.f) * p.code_step - p.delta;
+                    const float v_mfma = (float)p.dst[o2] + (dist < 0.f ? 1.f : 0.f) + dist;
+                    const float dev = v_mfma - temp;
+                    atomicMax(&s_maxdev, __float_as_uint(fabsf(dev - rintf(dev))));
+                    if (p.dst[o2] != qv) { p.dst[o2] = qv; atomicAdd(&s_changed, 1u); }
+                }
             }
         }
     }
@@ -584,8 +653,8 @@ hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st)
     hipLaunchKernelGGL(fix_collect_kernel, dim3((unsigned)(bands * segs * p.n_frames)), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // four workgroups per CU (128 VGPRs, 39 KB of LDS each) = all of them resident; they draw items from FIX_NEXT_ITEM
-    hipLaunchKernelGGL(fix_apply_kernel, dim3((unsigned)(4 * n_cu)), dim3(256), 0, st, p);
+    // every workgroup the GPU holds at once (5 per CU: <= 102 VGPRs, 26 KB of LDS each); they draw items from FIX_NEXT_ITEM
+    hipLaunchKernelGGL(fix_apply_kernel, dim3((unsigned)(5 * n_cu)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

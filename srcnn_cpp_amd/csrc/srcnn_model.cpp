@@ -194,7 +194,9 @@ int upload_weights(srcnn_ctx *c, const float *k99, const float *b99, const float
     const float *w3 = k55 ? k55 : zero_w.data();
     std::vector<float> frag((size_t)NFRAG * 64);
     pack_fragments(w1, b1, w2, b2, w3, frag.data());
-    std::vector<float> raw(8129 + 2048 + 5184);     // + W2 transposed [64][32] for the exact layer-1/2 kernel, + W1 transposed [81][64] (fix-up)
+    // + W2 transposed [64][32] for the exact layer-1/2 kernel, + W1 transposed [81][64] (fix-up), + one tap of zeros: the fix-up
+    // fetches a tap's weights one tap ahead, the last fetch lands here
+    std::vector<float> raw(8129 + 2048 + 5184 + 64, 0.f);
     std::memcpy(raw.data(), b1, 64 * 4);
     std::memcpy(raw.data() + 64, w1, 5184 * 4);
     std::memcpy(raw.data() + 5248, b2, 32 * 4);
