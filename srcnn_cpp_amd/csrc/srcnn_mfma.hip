@@ -735,10 +735,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     fo[s * FW] = R[3][s] + t[5 * s + 4];
+#ifndef SRCNN_ABL_NO_CHAIN_ADDS      // timing experiment only (wrong pixels): the upper bound of what in-place layer-3 accumulation could save
                     R[3][s] = R[2][s] + t[5 * s + 3];
                     R[2][s] = R[1][s] + t[5 * s + 2];
                     R[1][s] = R[0][s] + t[5 * s + 1];
                     R[0][s] = t[5 * s];
+#endif
                     // pin the update HERE: left alone, the optimiser sinks the adds into the next row (their first use)
                     // and keeps the 16 registers of t alive across the barrier
                     asm volatile("" : "+v"(R[0][s]), "+v"(R[1][s]), "+v"(R[2][s]), "+v"(R[3][s]));
