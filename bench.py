@@ -571,6 +571,14 @@ def worker(args):
             "prewarm": {"ms": args.prewarm_ms, "steps": prewarm_steps,
                         "why": "untimed clock ramp before the W warm-up steps; an idle GPU runs its first ~20 launches slower"},
         }
+        if args.path == "host":
+            # what crosses PCIe per step: every frame once each way (u8 in, u8 out); both directions run at the same time in the
+            # frame pipeline, so the rate each direction must sustain is bytes / time
+            gb = W * H * F * world / 1e9
+            out["pcie"] = {"bytes_each_way_per_frame": W * H, "h2d_gbps": round(gb / (elapsed / args.steps), 2),
+                           "d2h_gbps": round(gb / (elapsed / args.steps), 2),
+                           "what": "host frames (pageable numpy memory) through srcnn_forward_y" + ("_frames: pinned staging, "
+                                   "H2D + kernel + D2H of neighbouring frames overlapped on two lanes" if F > 1 else ": row bands")}
         if pmc_ref:
             out["pmc_reference"] = pmc_ref
         if world > 1:

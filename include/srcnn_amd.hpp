@@ -65,18 +65,21 @@ struct Plane {
 // from a single worker thread, src/srcnn.cpp:720).
 class Session {
 public:
-    explicit Session(int device = 0)
+    explicit Session(int device = 0) : h_(std::make_shared<Handle>())
     {
-        int rc = srcnn_create(&ctx_, device);
+        int rc = srcnn_create(&h_->ctx, device);
         if (rc != SRCNN_OK) throw Error(rc, "srcnn_create failed (a gfx950 GPU is required)");
     }
-    ~Session() { srcnn_destroy(ctx_); }
     Session(const Session &) = delete;
     Session &operator=(const Session &) = delete;
-    srcnn_ctx *get() const { return ctx_; }
+    srcnn_ctx *get() const { return h_->ctx; }
+    // The context is destroyed when the Session AND every device allocation made through it are gone: a DevicePlane that
+    // outlives its Session (a static vector, a vector handed to another thread that outlives the allocating one) keeps the
+    // context alive through this handle instead of freeing into a destroyed one.
+    std::shared_ptr<void> keep_alive() const { return h_; }
     void check(int rc) const
     {
-        if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(ctx_));
+        if (rc != SRCNN_OK) throw Error(rc, srcnn_last_error(h_->ctx));
     }
     static Session &thread_default()
     {
@@ -85,7 +88,14 @@ public:
     }
 
 private:
-    srcnn_ctx *ctx_ = nullptr;
+    struct Handle {
+        srcnn_ctx *ctx = nullptr;
+        Handle() = default;
+        Handle(const Handle &) = delete;
+        Handle &operator=(const Handle &) = delete;
+        ~Handle() { srcnn_destroy(ctx); }
+    };
+    std::shared_ptr<Handle> h_;
 };
 
 namespace detail {
@@ -156,7 +166,7 @@ inline void Convolution99x11(MatU8 &src, std::vector<MatF32> &dst,
 //
 // DevicePlane has cv::Mat's field names (rows, cols, step, data) but `data` is a DEVICE address; the planes of one
 // DevicePlanes() call share one allocation on the calling thread's Session (plane k at k * rows * cols elements), which
-// is freed when the last of them goes away -- before its Session does.
+// is freed when the last of them goes away; the Session's context stays alive until then.
 template <class T>
 struct DevicePlane {
     int rows = 0, cols = 0;
@@ -183,7 +193,8 @@ inline std::vector<DevicePlane<T>> DevicePlanes(int n, int cols, int rows, Sessi
     void *p = nullptr;
     s.check(srcnn_dev_alloc(s.get(), sizeof(T) * pitch * n, &p));
     srcnn_ctx *ctx = s.get();
-    std::shared_ptr<void> owner(p, [ctx](void *q) { (void)srcnn_dev_free(ctx, q); });
+    // (the deleter holds the Session's context alive: see Session::keep_alive)
+    std::shared_ptr<void> owner(p, [ctx, keep = s.keep_alive()](void *q) { (void)srcnn_dev_free(ctx, q); });
     std::vector<DevicePlane<T>> v(static_cast<std::size_t>(n));
     for (int k = 0; k < n; ++k) {
         v[k].rows = rows;

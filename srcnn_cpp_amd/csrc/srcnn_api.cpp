@@ -228,7 +228,7 @@ int srcnn_dev_free(srcnn_ctx *c, void *p)
 {
     BIND(c);
     if (!p) return SRCNN_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));          // queued work may still use it
+    HIP_TRY(c, hipDeviceSynchronize());                   // work queued on ANY stream the context was given may still use it
     HIP_TRY(c, hipFree(p));
     return SRCNN_OK;
 }

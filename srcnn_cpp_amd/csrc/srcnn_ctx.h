@@ -87,22 +87,35 @@ public:
             if (w->th.joinable()) w->th.join();
         }
     }
-    // fn(k) for k = 0 .. n - 1: k = 0 on the calling thread, the others on the parked workers; returns the first non-zero code
+    // fn(k) for k = 0 .. n - 1: k = 0 on the calling thread, the others on the parked workers; returns the first non-zero code.
+    // Every missing worker is created BEFORE any task is posted, and nothing is thrown to the caller (the C ABI sits right
+    // above): a thread or an allocation that cannot be had returns `nomem` with no task started -- no worker is left running a
+    // task that refers to this frame.
     template <typename Fn>
-    int run(int n, Fn fn)
+    int run(int n, Fn fn, int nomem = SRCNN_ERR_NOMEM)
     {
-        while ((int)workers_.size() < n - 1) {
-            workers_.emplace_back(new Worker());
-            Worker *w = workers_.back().get();
-            w->th = std::thread(loop, w);
+        try {
+            while ((int)workers_.size() < n - 1) {
+                std::unique_ptr<Worker> w(new Worker());
+                w->th = std::thread(loop, w.get());
+                workers_.push_back(std::move(w));
+            }
+        } catch (...) {
+            return nomem;
         }
-        for (int k = 1; k < n; ++k) {
-            Worker *w = workers_[(size_t)k - 1].get();
-            { std::lock_guard<std::mutex> lk(w->m); w->task = [&fn, k] { return fn(k); }; w->has_task = true; w->done = false; }
-            w->cv.notify_all();
+        int posted = 0, first = 0;
+        try {
+            for (int k = 1; k < n; ++k) {
+                Worker *w = workers_[(size_t)k - 1].get();
+                { std::lock_guard<std::mutex> lk(w->m); w->task = [&fn, k] { return fn(k); }; w->has_task = true; w->done = false; }
+                w->cv.notify_all();
+                posted = k;
+            }
+            first = fn(0);
+        } catch (...) {
+            first = nomem;             // (std::function may allocate; fn itself is this library's code and does not throw)
         }
-        int first = fn(0);
-        for (int k = 1; k < n; ++k) {
+        for (int k = 1; k <= posted; ++k) {       // whatever happened above, every posted task is waited for before this frame goes
             Worker *w = workers_[(size_t)k - 1].get();
             std::unique_lock<std::mutex> lk(w->m);
             w->cv.wait(lk, [w] { return w->done; });

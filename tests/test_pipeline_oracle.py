@@ -102,3 +102,46 @@ def test_cubic_resize_properties():
     ramp = np.tile(np.arange(0, 200, 4, dtype=np.uint8), (6, 1))
     r2 = oracle.resize_cubic(ramp, 100, 12)
     assert (np.diff(r2[3].astype(int))[4:-4] >= 0).all()                    # monotone ramp stays monotone inside
+
+
+# ---- what the pin above does NOT cover, bounded independently ------------------------------------------
+# The restatement of cv::resize (oracle/opencv_steps.c) is pinned bit for bit by ONE picture at ONE scale (x1.5, above).  Other
+# scales exercise other coefficient phases of the same code; no OpenCV exists in this image to pin them.  What can be checked
+# without it: the restatement against an independent float64 bicubic (Keys kernel, a = -0.75, half-pixel centres, replicate
+# border -- the definition OpenCV's INTER_CUBIC implements in 11-bit fixed point / float32).  A wrong coefficient phase,
+# offset or border rule moves values by many grey levels; fixed-point coefficients and intermediate roundings by less than one.
+
+def _bicubic_float64(src, dw, dh, a=-0.75):
+    sh, sw = src.shape
+
+    def axis(n_src, n_dst):
+        f = (np.arange(n_dst) + 0.5) * n_src / n_dst - 0.5
+        s = np.floor(f).astype(int)
+        t = f - s
+        w = np.stack([((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a,
+                      ((a + 2) * t - (a + 3)) * t * t + 1,
+                      ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1], -1)
+        w = np.concatenate([w, 1 - w.sum(-1, keepdims=True)], -1)
+        return np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1), w
+    xi, xw = axis(sw, dw)
+    yi, yw = axis(sh, dh)
+    h = (src.astype(np.float64)[:, xi] * xw[None]).sum(-1)
+    return np.clip((h[yi] * yw[:, :, None]).sum(1), 0, 255)
+
+
+@pytest.mark.parametrize("scale", [2.0, 3.0, 1.5, 1.3])
+def test_resize_restatement_against_float64_bicubic(scale):
+    """x2.0 is the scale of every BASELINE GPU configuration: there the restatement IS the rounded float64 bicubic (the
+    coefficient phases 1/4 and 3/4 are exact in 11 bits).  At x3.0, x1.5 and x1.3 it stays within one grey level of it."""
+    from srcnn_cpp_amd.synth import synth_luma
+    rng = np.random.default_rng(1)
+    planes = [synth_luma(320, 180, frame=2), rng.integers(0, 256, (97, 131), dtype=np.uint8),
+              np.fromfile(GOLD / "butterfly_y_in_576.u8", np.uint8).reshape(576, 576)[:200, :300].copy()]
+    for src in planes:
+        sh, sw = src.shape
+        dw, dh = oracle.scaled_size(sw, sh, scale)
+        got = oracle.resize_cubic(src, dw, dh)
+        ref = _bicubic_float64(src, dw, dh)
+        assert np.abs(got.astype(np.float64) - ref).max() < 1.0
+        if scale == 2.0:
+            assert np.array_equal(got, np.rint(ref).astype(np.uint8))

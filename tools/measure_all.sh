@@ -12,6 +12,8 @@ run --steps 20 --width 7680 --height 4320                       # configs[3] pla
 run --steps 5 --width 5760 --height 3240 --frames 8             # configs[4] frames (8 of the 512) on one GPU
 run --steps 20 --width 576 --height 576                         # configs[0] plane on the GPU
 run --steps 5 --path host --frames 32                           # stream of host frames, transfers overlapped
+run --steps 5 --path host --width 5760 --height 3240 --frames 8  # configs[4] as the host sees it: 8 of the 512 frames from pageable memory
+run --steps 3 --path host --width 5760 --height 3240 --frames 64 # ... 64 of them
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
 run --steps 3 --warmup 1 --path surface                         # the reference call surface on host buffers (32 f32 planes over PCIe)
 run --steps 10 --path surface-dev                              # the same two call sites with the 32 planes kept on the device (DevicePlane<float>)
