@@ -21,10 +21,12 @@ KERNEL = {"mfma": ["srcnn_strip_kernel", "srcnn_seams_merged_kernel", "srcnn_sea
 
 
 def writes_flags(name):
-    """The SRCNN_MODE_REFBYTES instantiations (last template argument FIX = true) also run in a default bench -- its `refbytes`
+    """The SRCNN_MODE_REFBYTES instantiations (template argument FIX = true) also run in a default bench -- its `refbytes`
     leg -- and store a flag plane besides: they are not the kernels of the float32 headline step."""
     m = re.search(r"<([^<>]*)>\(", name)
-    return bool(m) and m.group(1).split(",")[-1].strip() == "true"
+    args = [a.strip() for a in m.group(1).split(",")] if m else []
+    # srcnn_strip_kernel<MODE, PRE, DIAG, FIX, HALO3>; the seam kernels' FIX is their last argument
+    return bool(args) and (args[3] == "true" if len(args) >= 5 else args[-1] == "true")
 
 
 traffic_rec = {}

@@ -52,6 +52,9 @@ python tools/diag_light.py 7680 4320 > $OUT/diag_light_8k.txt 2>&1
 python tools/evt_test.py > $OUT/clock_ramp.txt 2>&1
 python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
 tools/stripe_overhead.sh $OUT/stripe_overhead.txt > /dev/null 2>&1
+python tools/stripe_projection.py > $OUT/stripe_projection.txt 2>&1
+python tools/stripe_projection.py --diag > $OUT/stripe_projection_diag.txt 2>&1
+python tools/stripe_projection.py --mode refbytes --ns 1,8 > $OUT/stripe_projection_refbytes.txt 2>&1
 python tests/checks/soak.py 120 31 > $OUT/soak.txt 2>&1
 python tests/checks/soak_paths.py 60 37 > $OUT/soak_paths.txt 2>&1
 python tests/checks/soak_models.py 240 3 > $OUT/soak_models.txt 2>&1
