@@ -779,7 +779,8 @@ def worker_cxx(args):
         "host_us_per_step": round(host_us, 2),
         "cold_start": cold,
         "distributed": {"control_plane": "none (one process)",
-                        "halo_transport": ({1: "copy kernel (contexts share a device)", 2: "hipMemcpyPeerAsync with peer access (xGMI)",
+                        "halo_transport": ({1: "none: the contexts share a device, the kernel reads the neighbours' rows where they lie",
+                                            2: "peer access: the kernel loads the neighbours' 6 edge rows over xGMI, no copy",
                                             3: "hipMemcpyPeerAsync WITHOUT peer access: staged through host memory by the runtime"}
                                            .get(max(c.halo_transport() for c in ctxs), "none (one stripe)")
                                            if stripe else "none (frames are independent)"),
