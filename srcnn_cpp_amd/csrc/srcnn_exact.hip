@@ -198,9 +198,8 @@ __device__ __forceinline__ void exact_layers12(const float (&px)[81], const floa
 {
     const cfloat_p weights = as_constant(weights_), w2t = as_constant(w2t_);
     const cfloat_p b1 = weights, w1 = weights + 64, b2 = w1 + 64 * 81;
-    f32x2 r2[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) r2[k] = f32x2{0.f, 0.f};
+    for (int k = 0; k < 32; ++k) r[k] = 0.f;
 #pragma unroll 1
     for (int i = 0; i < 64; ++i) {
         const cfloat_p wi = w1 + i * 81;
@@ -212,20 +211,18 @@ __device__ __forceinline__ void exact_layers12(const float (&px)[81], const floa
         }
         a = a + b1[i];
         a = (a < 0) ? 0.f : a;
-        // layer 2: two output channels per packed instruction, the weights as a scalar-register pair (each half is the plain
-        // instruction's rounded product and rounded add)
+        // (layer 2 packed two output channels per instruction, as the fix-up kernel does it: 2.79 -> 2.83 ms here, round 4 -- this
+        // kernel is bound by its dependent layer-1 chain, not by instruction issue)
         const cfloat_p w2i = w2t + i * 32;
-        const f32x2 aa = {a, a};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const f32x2 wk = {w2i[2 * k], w2i[2 * k + 1]};
-            const f32x2 pr = wk * aa;
-            r2[k] = r2[k] + pr;
+        for (int k = 0; k < 32; ++k) {
+            const float pr = a * w2i[k];
+            r[k] = r[k] + pr;
         }
     }
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-        float v = ((k & 1) ? r2[k >> 1].y : r2[k >> 1].x) + b2[k];
+        float v = r[k] + b2[k];
         r[k] = (v < 0) ? 0.f : v;
     }
 }
