@@ -233,12 +233,14 @@ def parse_args():
                     help="frames: independent planes per rank, no collective, weak scaling (default); "
                          "stripe: ONE width x height plane row-striped over the ranks with a 6-row "
                          "point-to-point halo exchange per step, strong scaling (BASELINE configs[3])")
-    ap.add_argument("--stripe-form", choices=["halo", "bands", "assemble"], default="halo",
+    ap.add_argument("--stripe-form", choices=["halo", "peer", "bands", "assemble"], default="halo",
                     help="stripe workload, how a rank's step is launched: halo (default) = ONE launch on the stripe where it "
                          "lies, the received 6-row halos in small buffers of their own that alternate from step to step, so the "
                          "exchange of the next step overlaps this step's kernel (srcnn_forward_y_rows_halo_dev); bands = interior "
                          "rows first, then the two 6-row edge bands behind the exchange (rounds 2-3); assemble = exchange into a "
-                         "[halo | stripe | halo] buffer, then one launch")
+                         "[halo | stripe | halo] buffer, then one launch; peer = NO per-step exchange: every rank maps its neighbours' "
+                         "stripes once (HIP IPC) and its one launch reads their 6 edge rows where they lie, over xGMI "
+                         "(sharding.PeerStripeStep)")
     ap.add_argument("--no-overlap", action="store_true", help="stripe workload: the same as --stripe-form assemble")
     ap.add_argument("--prewarm-ms", type=float, default=400.0,
                     help="untimed device wake-up BEFORE the W warm-up steps: the same step, repeated for this long.  An idle "
@@ -299,7 +301,9 @@ def worker(args):
         # no collective for frames; for stripes the 6 halo rows go neighbour to neighbour over RCCL.
         dist.init_process_group("gloo")
         degraded = False
-        if args.backend == "nccl" and args.workload == "stripe":    # frames exchange nothing: no RCCL communicator is built for them
+        peer_form = args.workload == "stripe" and args.stripe_form == "peer" and not args.no_overlap
+        # (frames exchange nothing and the peer form maps the neighbours' stripes once: no RCCL communicator is built for them)
+        if args.backend == "nccl" and args.workload == "stripe" and not peer_form:
             import datetime
             try:
                 rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
@@ -357,11 +361,14 @@ def worker(args):
     stepper = None
     if stripe:      # band buffers, send views and the point-to-point op list are built ONCE (sharding.StripeStep)
         form = "assemble" if args.no_overlap else args.stripe_form
-        if args.mode not in ("mfma", "refbytes") and form == "halo":
+        if args.mode not in ("mfma", "refbytes") and form in ("halo", "peer"):
             form = "bands"              # the split-f16 kernels read one buffer only
-        stepper = sharding.StripeStep(d_in[0], d_out[0], H, world, rank, sharding.gpu_launch_rows(ctx), group=rccl,
-                                      overlap=form != "assemble", via_host=world > 1 and rccl is None,
-                                      launch_rows_halo=sharding.gpu_launch_rows_halo(ctx) if form == "halo" else None)
+        if form == "peer":
+            stepper = sharding.PeerStripeStep(ctx, frames[0], d_out[0], H, world, rank, group=None)     # control plane: the gloo group
+        else:
+            stepper = sharding.StripeStep(d_in[0], d_out[0], H, world, rank, sharding.gpu_launch_rows(ctx), group=rccl,
+                                          overlap=form != "assemble", via_host=world > 1 and rccl is None,
+                                          launch_rows_halo=sharding.gpu_launch_rows_halo(ctx) if form == "halo" else None)
     host_out = np.empty_like(frames[0])
     host_frames = np.empty_like(frames) if args.path == "host" and F > 1 else None
     if args.path == "pipeline":
@@ -584,7 +591,9 @@ def worker(args):
         if world > 1:
             out["degraded"] = bool(degraded)
             out["distributed"] = {"control_plane": "gloo", "rccl_world": rccl_world,
-                                  "halo_transport": (("rccl send/recv" if rccl is not None else "host-staged (gloo)")
+                                  "halo_transport": (("none per step: the neighbours' stripes are mapped once (HIP IPC), the kernel "
+                                                      "loads their 6 edge rows where they lie (xGMI between GPUs)" if form == "peer" else
+                                                      "rccl send/recv" if rccl is not None else "host-staged (gloo)")
                                                      if stripe else "none (frames are independent)"),
                                   "stripe_form": form if stripe else None,
                                   "halo_overlap": bool(stripe and form != "assemble")}
@@ -659,6 +668,8 @@ def worker(args):
             ctx.set_mode(S.MODE_MFMA)
         emit_line(out)
 
+    if stripe and isinstance(stepper, sharding.PeerStripeStep):
+        stepper.close()                # the neighbours' mappings go before the allocations do
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

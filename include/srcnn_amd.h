@@ -161,6 +161,15 @@ int srcnn_dev_free(srcnn_ctx *ctx, void *d_ptr);
 int srcnn_dev_download(srcnn_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 int srcnn_dev_upload(srcnn_ctx *ctx, void *d_dst, const void *src, size_t bytes);
 
+/* The same memory across PROCESSES of one node (one process per GPU): srcnn_ipc_export fills a 64-byte handle
+ * for an allocation made with srcnn_dev_alloc (the handle names the whole allocation: pass its base address); another process
+ * -- on the same or another GPU of the node -- turns it into a device address of its own with srcnn_ipc_open (accesses from
+ * another GPU travel over xGMI) and gives it back with srcnn_ipc_close before the owner frees the memory.  The ranks of a
+ * row-striped plane use this to read each other's 6 edge rows where they lie (srcnn_forward_y_rows_halo_dev). */
+int srcnn_ipc_export(srcnn_ctx *ctx, void *d_ptr, unsigned char handle[64]);
+int srcnn_ipc_open(srcnn_ctx *ctx, const unsigned char handle[64], void **d_ptr);
+int srcnn_ipc_close(srcnn_ctx *ctx, void *d_ptr);
+
 /* ---- whole path: what src/srcnn.cpp:602-627 does with the above ------------ */
 
 /* Upload the model once (any later call may replace it). */

@@ -129,6 +129,9 @@ def load_library() -> C.CDLL:
         "srcnn_dev_free": ([vp, vp], i),
         "srcnn_dev_download": ([vp, vp, vp, sz], i),
         "srcnn_dev_upload": ([vp, vp, vp, sz], i),
+        "srcnn_ipc_export": ([vp, vp, C.POINTER(C.c_ubyte * 64)], i),
+        "srcnn_ipc_open": ([vp, C.POINTER(C.c_ubyte * 64), C.POINTER(vp)], i),
+        "srcnn_ipc_close": ([vp, vp], i),
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
         "srcnn_fixup_stats": ([vp, C.POINTER(C.c_ulonglong * 4), C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
         "srcnn_set_fixup_strict": ([vp, i], i),
@@ -159,7 +162,7 @@ ABI_SYMBOLS = (
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
-    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
@@ -350,6 +353,27 @@ class Context:
             raise ValueError("dst: expected a writeable C-contiguous numpy array")
         self._check(self._lib.srcnn_dev_download(self._h, dst.ctypes.data_as(C.c_void_p), d_src, dst.nbytes))
         return dst
+
+    def dev_upload(self, d_dst: int, src: np.ndarray):
+        src = np.ascontiguousarray(src)
+        self._check(self._lib.srcnn_dev_upload(self._h, d_dst, src.ctypes.data_as(C.c_void_p), src.nbytes))
+
+    # device memory shared with the other ranks of the node (srcnn_ipc_*): a 64-byte handle out, a device address in
+    def ipc_export(self, d_ptr: int) -> bytes:
+        h = (C.c_ubyte * 64)()
+        self._check(self._lib.srcnn_ipc_export(self._h, d_ptr, C.byref(h)))
+        return bytes(h)
+
+    def ipc_open(self, handle: bytes) -> int:
+        if len(handle) != 64:
+            raise ValueError("an IPC handle is 64 bytes")
+        h = (C.c_ubyte * 64).from_buffer_copy(handle)
+        p = C.c_void_p()
+        self._check(self._lib.srcnn_ipc_open(self._h, C.byref(h), C.byref(p)))
+        return p.value
+
+    def ipc_close(self, d_ptr: int):
+        self._check(self._lib.srcnn_ipc_close(self._h, d_ptr))
 
     def conv99x11_to_dev(self, src, d_planes, plane_stride, plane_pitch, k99, b99, k11, b11):
         src, ss = _plane(src, np.uint8, "src")

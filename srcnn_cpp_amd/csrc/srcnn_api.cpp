@@ -251,6 +251,41 @@ int srcnn_dev_upload(srcnn_ctx *c, void *d_dst, const void *src, size_t bytes)
     return SRCNN_OK;
 }
 
+/* Device memory shared between PROCESSES on one node (one process per GPU): the owner exports a handle of an allocation made
+ * with srcnn_dev_alloc, a neighbour opens it and gets a device address valid in ITS process -- on another GPU the accesses go
+ * over xGMI.  This is how the ranks of a row-striped plane read each other's 6 edge rows where they lie instead of exchanging
+ * them every step (srcnn_forward_y_rows_halo_dev takes such addresses as its halo pointers). */
+int srcnn_ipc_export(srcnn_ctx *c, void *d_ptr, unsigned char handle[64])
+{
+    BIND(c);
+    if (!d_ptr || !handle) return fail(c, SRCNN_ERR_INVALID, "ipc_export: null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI carries the handle as 64 bytes");
+    hipIpcMemHandle_t h;
+    HIP_TRY(c, hipIpcGetMemHandle(&h, d_ptr));
+    std::memcpy(handle, &h, sizeof(h));
+    return SRCNN_OK;
+}
+
+int srcnn_ipc_open(srcnn_ctx *c, const unsigned char handle[64], void **d_ptr)
+{
+    BIND(c);
+    if (!d_ptr || !handle) return fail(c, SRCNN_ERR_INVALID, "ipc_open: null pointer");
+    *d_ptr = nullptr;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    HIP_TRY(c, hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return SRCNN_OK;
+}
+
+int srcnn_ipc_close(srcnn_ctx *c, void *d_ptr)
+{
+    BIND(c);
+    if (!d_ptr) return SRCNN_OK;
+    HIP_TRY(c, hipDeviceSynchronize());                   // queued work may still read through the mapping
+    HIP_TRY(c, hipIpcCloseMemHandle(d_ptr));
+    return SRCNN_OK;
+}
+
 #ifdef SRCNN_TUNING_BUILD
 /* ---- test / diagnostics hooks: tuning build only, not part of the ABI ---- */
 

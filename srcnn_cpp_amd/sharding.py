@@ -377,6 +377,73 @@ class StripeStep:
     __call__ = step
 
 
+class PeerStripeStep:
+    """The row-striped step of ONE plane on this rank WITHOUT a per-step exchange: every rank maps its neighbours' stripes into
+    its own address space once (HIP IPC handles of the allocations, exchanged over the control-plane group) and its one launch
+    reads their 6 edge rows where they lie -- between GPUs that is 46 KB of loads over xGMI in the prologue of the workgroups at
+    the stripe's edges (``srcnn_forward_y_rows_halo_dev`` takes the mapped addresses as its halo pointers).  What the one-process
+    host does with peer access (``srcnn_forward_y_striped_dev``), for one process per GPU.
+
+    The stripe lives in an allocation of its own (``Context.dev_alloc``: an IPC handle names a whole allocation); ``upload()``
+    refills it.  A neighbour READS this rank's edge rows during its step, so a new plane may be uploaded only after every
+    rank has finished the step on the old one (``barrier()``); the bench's input is resident and constant.
+    """
+
+    def __init__(self, ctx, stripe_rows_np, out, height: int, world: int, rank: int, group=None):
+        import torch.distributed as dist
+
+        self.ctx, self.out, self.height, self.world, self.rank, self.group = ctx, out, height, world, rank, group
+        self.r0, self.r1 = stripe_rows(height, world, rank)
+        self.width = int(stripe_rows_np.shape[1])
+        if stripe_rows_np.shape[0] != self.r1 - self.r0:
+            raise ValueError(f"rank {rank}: stripe has {stripe_rows_np.shape[0]} rows, owns [{self.r0},{self.r1})")
+        if world > 1 and min(b - a for a, b in (stripe_rows(height, world, k) for k in range(world))) < HALO_ROWS:
+            raise ValueError("stripes thinner than the halo: use fewer ranks for this plane")
+        self.d_stripe = ctx.dev_alloc((self.r1 - self.r0) * self.width)
+        self.upload(stripe_rows_np)
+        self.top = self.bot = 0
+        self._mapped = []
+        if world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, ctx.ipc_export(self.d_stripe), group=group)
+            if rank > 0:
+                a0, a1 = stripe_rows(height, world, rank - 1)
+                base = ctx.ipc_open(handles[rank - 1])
+                self._mapped.append(base)
+                self.top = base + (a1 - a0 - HALO_ROWS) * self.width          # the upper neighbour's last 6 rows
+            if rank < world - 1:
+                base = ctx.ipc_open(handles[rank + 1])
+                self._mapped.append(base)
+                self.bot = base                                                # the lower neighbour's first 6 rows
+            dist.barrier(group=group)       # every stripe is uploaded before anybody's first step reads a neighbour's rows
+
+    def upload(self, stripe_rows_np):
+        self.ctx.dev_upload(self.d_stripe, stripe_rows_np)
+
+    def step(self):
+        """One step: ONE launch, asynchronous on the context's stream."""
+        out, w = self.out, self.width
+        self.ctx.forward_y_rows_halo_dev(self.d_stripe, w, self.r0, self.r1 - self.r0, self.top, self.bot, w,
+                                         out.data_ptr(), out.stride(0), self.r0, w, self.height, self.r0, self.r1)
+        return out
+
+    __call__ = step
+
+    def close(self):
+        import torch.distributed as dist
+        self.ctx.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)  # nobody reads this rank's rows any more
+        for base in self._mapped:
+            self.ctx.ipc_close(base)
+        self._mapped = []
+        if self.world > 1:
+            dist.barrier(group=self.group)  # every mapping of this rank's allocation is gone before it is freed
+        if self.d_stripe:
+            self.ctx.dev_free(self.d_stripe)
+            self.d_stripe = 0
+
+
 def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,
                            group=None, overlap: bool = True, via_host: bool = False, launch_rows_halo: Optional[Callable] = None):
     """One row-striped step of ONE plane (a ``StripeStep`` built and run once; callers that step repeatedly keep

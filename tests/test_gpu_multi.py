@@ -42,11 +42,12 @@ def test_bench_two_ranks_frames_equal_one_rank():
     assert two["value"] > 0 and two["roofline"]["frac"] > 0
 
 
-@pytest.mark.parametrize("form", ["halo", "bands", "assemble"])
+@pytest.mark.parametrize("form", ["halo", "peer", "bands", "assemble"])
 def test_bench_two_ranks_stripe_equal_one_rank(form):
     """configs[3] shape: one plane, two ranks, 6-row halo exchange; the stitched plane equals the 1-rank plane, whichever way
-    a rank launches its step (one launch with the halo rows in buffers of their own -- the default --, interior rows + edge
-    bands, or one launch on an assembled copy)."""
+    a rank launches its step (one launch with the halo rows in buffers of their own -- the default --, one launch that reads
+    the neighbour's rows through a HIP IPC mapping of its stripe with no per-step exchange at all, interior rows + edge bands,
+    or one launch on an assembled copy)."""
     w, h = 1920, 1080
     one = run_bench("--gpus", 1, "--workload", "stripe", "--width", w, "--height", h)
     two = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--workload", "stripe", "--width", w, "--height", h,
