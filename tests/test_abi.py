@@ -149,6 +149,9 @@ def test_null_and_bad_arguments(lib):
     assert lib.srcnn_get_mode(None) == -1
     assert lib.srcnn_last_error(None) == b"null context"
     lib.srcnn_destroy(None)                                    # harmless
+    assert lib.srcnn_kernel_variant(None) == -1 and lib.srcnn_halo_transport(None) == -1
+    assert lib.srcnn_ipc_export(None, None, None) == -1 and lib.srcnn_ipc_open(None, None, None) == -1
+    assert lib.srcnn_set_fixup_strict(None, 1) == -1
 
 
 def test_python_binding_validates_planes():

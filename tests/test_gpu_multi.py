@@ -73,15 +73,47 @@ def ctx_pool(weights_blob):
 
 @pytest.mark.parametrize("n_ctx,w,h", [(2, 260, 90), (3, 260, 90), (3, 131, 20), (2, 3840, 2160), (3, 1000, 37)])
 def test_striped_over_contexts_equals_single_context(gpu_ctx, ctx_pool, n_ctx, w, h):
-    """srcnn_forward_y_striped: own rows per context, halo rows device to device, interior rows first, edge bands
-    after the copies (stripes thinner than 18 rows take the assemble-then-launch path) -- same bytes as one context."""
+    """srcnn_forward_y_striped: own rows per context, ONE launch per stripe that reads the neighbours' 6 edge rows where they
+    lie (stripes of 6 .. 17 rows included: 131x20 over 3, 1000x37 over 3) -- same bytes as one context."""
     y = synth_luma(w, h, frame=4)
     whole = gpu_ctx.forward_y(y)
     got = S.forward_y_striped(ctx_pool[:n_ctx], y)
     assert np.array_equal(got, whole)
-    # twice in a row: the band buffers of step 1 are reused by step 2 (ordered by events, not by a host wait)
     y2 = synth_luma(w, h, frame=5)
     assert np.array_equal(S.forward_y_striped(ctx_pool[:n_ctx], y2), gpu_ctx.forward_y(y2))
+
+
+@pytest.mark.parametrize("n_ctx,w,h", [(2, 260, 90), (3, 131, 20), (3, 1920, 400)])
+def test_striped_in_the_split_f16_mode_keeps_the_band_form(weights_blob, n_ctx, w, h):
+    """The split-f16 kernels read one buffer only: in SRCNN_MODE_SPLIT16 the striped step still copies the halo rows on a
+    second stream and launches interior rows + edge bands (thin stripes: one launch on an assembled copy) -- same bytes as one
+    context in that mode, twice in a row (the band buffers of step 1 are reused by step 2, ordered by events)."""
+    ctxs = [S.Context(0) for _ in range(n_ctx)]
+    try:
+        for c in ctxs:
+            c.set_weights_blob(weights_blob)
+            c.set_mode(S.MODE_SPLIT16)
+        for frame in (4, 5):
+            y = synth_luma(w, h, frame=frame)
+            assert np.array_equal(S.forward_y_striped(ctxs, y), ctxs[0].forward_y(y))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_bench_four_ranks_on_one_gpu():
+    """The launcher, the gloo control plane (barrier, common start instant, gathers) and both workloads with FOUR ranks (they
+    share the box's one GPU): output planes equal to what one rank computes."""
+    w, h = 1280, 720
+    one = run_bench("--gpus", 1, "--frames", 4, "--width", w, "--height", h)
+    four = run_bench("--gpus", 4, "--shared-gpu", "--backend", "gloo", "--width", w, "--height", h)
+    assert four["n_gpus"] == 4 and len(four["per_rank_ms_per_step"]) == 4
+    assert four["config"]["output_crc32"] == one["config"]["output_crc32"]
+    plane = run_bench("--gpus", 1, "--workload", "stripe", "--width", w, "--height", h)
+    for form in ("halo", "peer"):
+        striped = run_bench("--gpus", 4, "--shared-gpu", "--backend", "gloo", "--workload", "stripe", "--stripe-form", form,
+                            "--width", w, "--height", h)
+        assert striped["n_gpus"] == 4 and striped["config"]["output_crc32"] == plane["config"]["output_crc32"], form
 
 
 def test_striped_dev_back_to_back(gpu_ctx, ctx_pool):
