@@ -197,6 +197,7 @@ struct srcnn_ctx {
     bool halo_free_set[kHaloSets] = {false, false, false, false};
     unsigned long stripe_steps = 0;
     int halo_transport = 0;                // srcnn_halo_transport(): 0 none yet, 1 same device, 2 peer access (xGMI), 3 staged by the runtime
+    std::vector<int> peer_state;           // per device id: 0 not asked yet, 2 peer access enabled, 3 refused
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     srcnn::host::DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging

@@ -22,7 +22,7 @@ int srcnn_stripe_rows(int height, int n_parts, int index, int *row_begin, int *r
 
 namespace {
 
-constexpr int kHalo = 6;       // 4 input rows of the 9x9 layer + 2 feature rows of the 5x5 layer
+constexpr int kHalo = kHaloRows;
 
 int check_ctx_set(srcnn_ctx *const *ctxs, int n_ctx)
 {
@@ -52,38 +52,46 @@ hipError_t copy_rows_between(srcnn_ctx *to, uint8_t *dst, size_t dst_stride, con
     return hipSuccess;
 }
 
-// The streams and events of the striped step, and the link to the neighbouring devices: peer access is asked for ONCE and the
-// answer kept -- a refused link still works (hipMemcpyPeerAsync then stages through host memory) but is not the xGMI path
-// BASELINE configs[3] names, so the context says so (srcnn_halo_transport(), srcnn_last_error()).
+// The streams and events of the striped step (created once per context) and the links to the neighbouring devices: peer access
+// is asked for ONCE PER DEVICE and the answer kept -- a refused link still works (hipMemcpyPeerAsync then stages through host
+// memory) but is not the xGMI path BASELINE configs[3] names, so the context says so (srcnn_halo_transport(),
+// srcnn_last_error()).  The neighbours are looked at on EVERY call: a context may serve in another set later.
 int stripe_setup(srcnn_ctx *const *ctxs, int n_ctx, int k)
 {
     srcnn_ctx *c = ctxs[k];
-    if (c->halo_stream) return SRCNN_OK;
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->bands_done, hipEventDisableTiming));
-    for (int i = 0; i < srcnn_ctx::kHaloSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->halo_free[i], hipEventDisableTiming));
-    c->halo_transport = 1;
+    if (!c->halo_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->bands_done, hipEventDisableTiming));
+        for (int i = 0; i < srcnn_ctx::kHaloSets; ++i) HIP_TRY(c, hipEventCreateWithFlags(&c->halo_free[i], hipEventDisableTiming));
+    }
+    int transport = 1;
     static const char *env_staged = SRCNN_DEBUG_ENV("SRCNN_DEBUG_HALO_STAGED");      // test knob: take the no-peer-access path
-    if (env_staged && std::atoi(env_staged)) c->halo_transport = 3;
+    if (env_staged && std::atoi(env_staged)) transport = 3;
     for (int n : {k - 1, k + 1}) {
         if (n < 0 || n >= n_ctx || ctxs[n]->device == c->device) continue;
-        int can = 0;
-        hipError_t e = hipDeviceCanAccessPeer(&can, c->device, ctxs[n]->device);
-        if (e == hipSuccess && can) {
-            e = hipDeviceEnablePeerAccess(ctxs[n]->device, 0);
-            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+        const int dev = ctxs[n]->device;
+        if ((int)c->peer_state.size() <= dev) c->peer_state.resize((size_t)dev + 1, 0);
+        if (c->peer_state[(size_t)dev] == 0) {
+            int can = 0;
+            hipError_t e = hipDeviceCanAccessPeer(&can, c->device, dev);
+            if (e == hipSuccess && can) {
+                e = hipDeviceEnablePeerAccess(dev, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            }
+            if (e == hipSuccess && can) {
+                c->peer_state[(size_t)dev] = 2;
+            } else {
+                (void)hipGetLastError();
+                c->peer_state[(size_t)dev] = 3;
+                (void)fail(c, SRCNN_OK, "row stripes: device %d has no peer access to device %d (%s): halo rows are staged through host "
+                                        "memory, not read over xGMI", c->device, dev,
+                           e == hipSuccess ? "hipDeviceCanAccessPeer says no" : hipGetErrorString(e));
+            }
         }
-        if (e == hipSuccess && can) {
-            c->halo_transport = std::max(c->halo_transport, 2);
-        } else {
-            (void)hipGetLastError();
-            c->halo_transport = 3;
-            (void)fail(c, SRCNN_OK, "row stripes: device %d has no peer access to device %d (%s): halo rows are staged through host "
-                                    "memory, not copied over xGMI", c->device, ctxs[n]->device,
-                       e == hipSuccess ? "hipDeviceCanAccessPeer says no" : hipGetErrorString(e));
-        }
+        transport = std::max(transport, c->peer_state[(size_t)dev]);
     }
+    c->halo_transport = transport;
     return SRCNN_OK;
 }
 
