@@ -195,8 +195,9 @@ int srcnn_forward_y_frames(srcnn_ctx *ctx, const uint8_t *const *src, size_t src
 /* ---- several GPUs driven from ONE host process ------------------ *
  * One context per GPU (several contexts on one GPU also work), one host thread   *
  * per context inside the call, no collective library: frames are independent,    *
- * and a row-striped plane needs only its neighbours' 6 boundary rows, copied     *
- * device to device (hipMemcpyPeerAsync over xGMI).  These serve the reference's  *
+ * and a row-striped plane needs only its neighbours' 6 boundary rows, which the   *
+ * kernel reads where they lie over xGMI (peer access; copies only on a link that  *
+ * refuses it: srcnn_halo_transport).  These serve the reference's                 *
  * two call sites src/srcnn.cpp:609,627 when the caller owns more than one GPU;   *
  * the reference's own parallelism is the row-parallel loop at :283-284, which    *
  * row striping generalises.  Every context needs srcnn_set_weights.              */

@@ -12,7 +12,8 @@ Writes  profiles/r04/fixup_adversarial.txt          the report (worst |v_gpu - v
         tests/golden/adversarial_windows.npz        the worst windows as fixtures (tests/test_adversarial.py on the CPU,
                                                     tests/test_gpu_refbytes.py on the GPU in both REFBYTES modes)
 
-usage: python tests/checks/fixup_adversarial.py [restarts_shipped=120000] [restarts_per_random_model=6000] [n_models=24]
+usage: python tests/checks/fixup_adversarial.py [restarts_shipped=120000] [restarts_per_random_model=6000] [n_models=24] [seed] [suffix]
+(a `suffix` writes profiles/r04/fixup_adversarial<suffix>.txt and leaves the fixture alone: a second, independent search)
 """
 import sys
 import time
@@ -113,6 +114,8 @@ def main():
     n_ship = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
     n_rand = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
     n_models = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 20261003
+    suffix = sys.argv[5] if len(sys.argv) > 5 else ""
     out_dir = ROOT / "profiles" / "r04"
     out_dir.mkdir(parents=True, exist_ok=True)
     lines = []
@@ -123,7 +126,7 @@ def main():
     log("# Adversarial search for the largest |v_gpu - v_ref| of one output pixel (tests/checks/fixup_adversarial.py,")
     log("# oracle/adversarial.c): coordinate ascent over the 13 x 13 luma window, CPU, both arithmetics bit-exact models.")
     log("# SRCNN_MODE_REFBYTES is exact while the deviation stays <= delta; the tests assert the monitor < delta / 2.")
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(seed)
     blob = S.load_weights()
     w, d, v, delta, ev_total = attack(blob, n_ship, rng, "shipped model (convdata.h)", log)
     fixture = {"shipped_windows": w[:64], "shipped_dev": d[:64], "shipped_vals": v[:64], "shipped_delta": np.float32(delta)}
@@ -135,11 +138,13 @@ def main():
         worst_ratio = max(worst_ratio, d2[0] / delta2)
         if m < 8:                                   # fixtures: the first 8 random models with their 8 worst windows
             blobs.append(mb); rw.append(w2[:8]); rd.append(d2[:8])
-    fixture.update(random_blobs=np.stack(blobs), random_windows=np.stack(rw), random_dev=np.stack(rd))
+    if blobs:
+        fixture.update(random_blobs=np.stack(blobs), random_windows=np.stack(rw), random_dev=np.stack(rd))
     log(f"# worst deviation / delta over all models: {worst_ratio:.3f}  (threshold for action: 0.5);"
         f" {ev_total / 1e6:.0f} M point evaluations in total")
-    np.savez_compressed(ROOT / "tests" / "golden" / "adversarial_windows.npz", **fixture)
-    (out_dir / "fixup_adversarial.txt").write_text("\n".join(lines) + "\n")
+    if not suffix:
+        np.savez_compressed(ROOT / "tests" / "golden" / "adversarial_windows.npz", **fixture)
+    (out_dir / f"fixup_adversarial{suffix}.txt").write_text("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":

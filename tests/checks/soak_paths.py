@@ -7,7 +7,10 @@ Convolution55 launch all engage with odd geometries); every result is compared B
 kernels' arithmetic (oracle.gpuorder_*):
   * srcnn_forward_y with and without the pre-clamp plane (the latter pipelines row bands on large planes)
   * a batch of 2-5 frames through srcnn_forward_y_dev (item plan repeated per frame) with padded strides / pitches
-  * the same plane row-striped over 2-3 contexts (srcnn_forward_y_striped)
+  * the same plane row-striped over 2-3 contexts (srcnn_forward_y_striped: one launch per stripe, neighbours' rows read in place)
+  * the same plane as 2-8 stripes through srcnn_forward_y_rows_halo_dev with the halo rows in separately allocated buffers of
+    another row stride -- in the MFMA mode (against the model) and in SRCNN_MODE_REFBYTES (against the reference arithmetic),
+    in strict mode every now and then with the threshold cut below the noise (the exact re-run path)
   * Convolution99x11 -> Convolution55 through the device entry points (aligned 128-column strips in the second)
 """
 import sys, time
@@ -57,6 +60,38 @@ while time.time() - t0 < budget:
     nc = int(rng.integers(2, 4))
     if h // nc >= 6:
         assert np.array_equal(S.forward_y_striped(ctxs[:nc], y), m_out), ("striped", w, h, nc)
+    # stripes with their halo rows in buffers of their own, both float32 modes
+    ns = int(rng.integers(2, 9))
+    if h // ns >= 6:
+        r_out = oracle.forward_y(y, blob)[0] if w * h <= 1_500_000 else None
+        for mode in ((S.MODE_MFMA, S.MODE_REFBYTES) if r_out is not None else (S.MODE_MFMA,)):
+            ctx.set_mode(mode)
+            strict = mode == S.MODE_REFBYTES and rng.random() < 0.3
+            if strict:
+                ctx.set_fixup_margin(0.25)
+                ctx.set_fixup_strict(True)
+            d_o = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+            keep = []
+            for k in range(ns):
+                r0, r1 = S.stripe_rows(h, ns, k)
+                hs = w + int(rng.integers(0, 3)) * 16
+                own = torch.from_numpy(np.ascontiguousarray(y[r0:r1])).cuda()
+                top = bot = None
+                if k > 0:
+                    top = torch.zeros((6, hs), dtype=torch.uint8, device="cuda"); top[:, :w] = torch.from_numpy(np.ascontiguousarray(y[r0 - 6:r0])).cuda()
+                if k < ns - 1:
+                    bot = torch.zeros((6, hs), dtype=torch.uint8, device="cuda"); bot[:, :w] = torch.from_numpy(np.ascontiguousarray(y[r1:r1 + 6])).cuda()
+                keep += [own, top, bot]
+                torch.cuda.synchronize()
+                ctx.forward_y_rows_halo_dev(own.data_ptr(), w, r0, r1 - r0, top.data_ptr() if top is not None else 0,
+                                            bot.data_ptr() if bot is not None else 0, hs, d_o.data_ptr(), w, 0, w, h, r0, r1)
+            ctx.synchronize()
+            want = m_out if mode == S.MODE_MFMA else r_out
+            assert np.array_equal(d_o.cpu().numpy(), want), ("halo stripes", mode, strict, w, h, ns)
+            if strict:
+                ctx.set_fixup_strict(False)
+                ctx.set_fixup_margin(6.0)
+        ctx.set_mode(S.MODE_MFMA)
     # the two reference functions on device memory
     if w * h <= 4_500_000:
         d_y = torch.from_numpy(y).cuda()
