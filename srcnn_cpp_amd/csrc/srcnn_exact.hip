@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
                                                            uint8_t *__restrict__ dst, float *__restrict__ pre,
                                                            long dstride, long dst_frame_pitch, int w, int h,
                                                            const float *__restrict__ kernel, float bias,
-                                                           int out_row0, int out_row1, int pl_row0, int dst_row0)
+                                                           int out_row0, int out_row1, int pl_row0, int pl_row1, int dst_row0)
 {
-    // output rows [out_row0, out_row1); planes points at map row pl_row0, dst / pre at image row dst_row0 (whole planes: 0, h, 0, 0)
+    // output rows [out_row0, out_row1); planes holds map rows [pl_row0, pl_row1), dst / pre point at image row dst_row0 (whole
+    // planes: 0, h, 0, h, 0).  A tile's window may reach past the rows the launch produces (its last tile is 4 rows tall whatever
+    // out_row1 is): such rows feed no pixel that is stored, and are clamped into the map rows that exist.
     constexpr int TW = 64, TH = 4, WW = TW + 4, WH = TH + 4, WN = WW * WH;   // 68 x 8 window
     __shared__ float win[2][WN];
     // (the weights are wave-uniform: they come through the scalar cache; from LDS: 2 % slower)
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(256) void conv55_exact_kernel(const float *__restri
         const int e = threadIdx.x + 256 * q;
         idx[q] = e < WN ? e : -1;
         const int wy = e / WW, wx = e % WW;
-        off[q] = (long)(clampi_e(row0 + wy - 2, 0, h - 1) - pl_row0) * stride + clampi_e(col0 + wx - 2, 0, w - 1);
+        off[q] = (long)(clampi_e(clampi_e(row0 + wy - 2, 0, h - 1), pl_row0, pl_row1 - 1) - pl_row0) * stride + clampi_e(col0 + wx - 2, 0, w - 1);
     }
     auto stage = [&](int ch, int buf) {
         const float *pl = pf + (long)ch * pitch;
@@ -704,14 +706,14 @@ hipError_t launch_conv99x11_exact_rows(const uint8_t *src, long sstride, int src
     return hipGetLastError();
 }
 
-// Output rows [row0, row1) of ONE frame from map rows [row0 - 2, row1 + 2) (clamped to the image): planes points at map row
-// pl_row0, dst at image row dst_row0.
-hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, uint8_t *dst, long dstride,
+// Output rows [row0, row1) of ONE frame from map rows [row0 - 2, row1 + 2) (clamped to the image): planes holds map rows
+// [pl_row0, pl_row1), dst points at image row dst_row0.
+hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, int pl_row1, uint8_t *dst, long dstride,
                                     int dst_row0, int w, int h, int row0, int row1, const float *d_kernel800, float bias,
                                     hipStream_t st)
 {
     hipLaunchKernelGGL(conv55_exact_kernel, px_grid(w, row1 - row0, 1), dim3(256), 0, st, planes, stride, pitch, 0L, dst,
-                       (float *)nullptr, dstride, 0L, w, h, d_kernel800, bias, row0, row1, pl_row0, dst_row0);
+                       (float *)nullptr, dstride, 0L, w, h, d_kernel800, bias, row0, row1, pl_row0, pl_row1, dst_row0);
     return hipGetLastError();
 }
 
@@ -720,7 +722,7 @@ hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, lon
                                const float *d_kernel800, float bias, hipStream_t st)
 {
     hipLaunchKernelGGL(conv55_exact_kernel, px_grid(w, h, n_frames), dim3(256), 0, st, planes, stride, pitch,
-                       frame_pitch, dst, pre, dstride, dst_frame_pitch, w, h, d_kernel800, bias, 0, h, 0, 0);
+                       frame_pitch, dst, pre, dstride, dst_frame_pitch, w, h, d_kernel800, bias, 0, h, 0, h, 0);
     return hipGetLastError();
 }
 

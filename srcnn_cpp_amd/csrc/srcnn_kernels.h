@@ -207,7 +207,7 @@ hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_fra
                                   int w, int h, int n_frames, const float *d_weights, hipStream_t st);
 hipError_t launch_conv99x11_exact_rows(const uint8_t *src, long sstride, int src_row0, float *planes, long stride, long pitch,
                                        int pl_row0, int w, int h, int row0, int row1, const float *d_weights, hipStream_t st);
-hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, uint8_t *dst, long dstride,
+hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, int pl_row1, uint8_t *dst, long dstride,
                                     int dst_row0, int w, int h, int row0, int row1, const float *d_kernel800, float bias,
                                     hipStream_t st);
 hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, long frame_pitch,

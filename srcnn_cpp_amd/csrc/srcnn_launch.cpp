@@ -62,7 +62,7 @@ int rerun_exact_rows(srcnn_ctx *c, const FixParams &f)
             src_row0 = yb;
         }
         HIP_TRY(c, launch_conv99x11_exact_rows(src, sstride, src_row0, work, f.width, pitch, fb, f.width, f.height, fb, fe, wraw, c->stream));
-        HIP_TRY(c, launch_conv55_exact_rows(work, f.width, pitch, fb, f.dst + (long)k * f.dst_frame_pitch, f.dst_stride, f.dst_row0,
+        HIP_TRY(c, launch_conv55_exact_rows(work, f.width, pitch, fb, fe, f.dst + (long)k * f.dst_frame_pitch, f.dst_stride, f.dst_row0,
                                             f.width, f.height, f.row_begin, f.row_end, wraw + 7329, c->b3, c->stream));
     }
     return SRCNN_OK;

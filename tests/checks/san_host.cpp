@@ -29,7 +29,7 @@ hipError_t launch_conv11_exact(const float *, long, long, float *, long, int, in
 hipError_t launch_conv99x11_exact(const uint8_t *, long, long, float *, long, long, long, int, int, int, const float *, hipStream_t) { return never(); }
 hipError_t launch_conv55_exact(const float *, long, long, long, uint8_t *, float *, long, long, int, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv99x11_exact_rows(const uint8_t *, long, int, float *, long, long, int, int, int, int, int, const float *, hipStream_t) { return never(); }
-hipError_t launch_conv55_exact_rows(const float *, long, long, int, uint8_t *, long, int, int, int, int, int, const float *, float, hipStream_t) { return never(); }
+hipError_t launch_conv55_exact_rows(const float *, long, long, int, int, uint8_t *, long, int, int, int, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_copy_rows(uint8_t *, long, const uint8_t *, long, int, int, hipStream_t) { return never(); }
 hipError_t launch_bgr2ycrcb(const uint8_t *, long, int, int, uint8_t *, long, long, hipStream_t) { return never(); }
 hipError_t launch_ycrcb2bgr(const uint8_t *, long, const uint8_t *, long, long, int, int, uint8_t *, long, hipStream_t) { return never(); }

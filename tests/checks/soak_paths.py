@@ -29,12 +29,18 @@ for c in ctxs:
     c.set_weights_blob(blob)
 ctx = ctxs[0]
 n, t0 = 0, time.time()
+import os
+os.makedirs("gpurun_out", exist_ok=True)
+progress = open("gpurun_out/soak_paths_progress.txt", "w")          # what was running when a launch faulted
+def note(*a):
+    progress.write(" ".join(map(str, a)) + "\n"); progress.flush()
 while time.time() - t0 < budget:
     w = int(rng.choice([rng.integers(130, 4100), rng.choice([128, 256, 260, 1020, 1024, 1028, 1920, 2047, 2052, 3840])]))
     h = int(rng.choice([rng.integers(40, 2300), rng.choice([64, 540, 1024, 1080, 2047, 2160])]))
     if w * h > 9_000_000:
         h = 9_000_000 // w
     y = synth_luma(w, h, frame=int(rng.integers(0, 99)))
+    note("plane", n, w, h)
     m_out, m_pre = oracle.gpuorder_forward_y(y, blob)
     pre = np.empty((h, w), np.float32)
     assert np.array_equal(ctx.forward_y(y, preclamp=pre), m_out) and np.array_equal(pre, m_pre), ("forward_y+pre", w, h)
@@ -67,6 +73,7 @@ while time.time() - t0 < budget:
         for mode in ((S.MODE_MFMA, S.MODE_REFBYTES) if r_out is not None else (S.MODE_MFMA,)):
             ctx.set_mode(mode)
             strict = mode == S.MODE_REFBYTES and rng.random() < 0.3
+            note("halo stripes", w, h, ns, mode, strict)
             if strict:
                 ctx.set_fixup_margin(0.25)
                 ctx.set_fixup_strict(True)

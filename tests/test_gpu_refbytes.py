@@ -342,3 +342,33 @@ def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
         before = ctx.fixup_stats()["exact_reruns"]
         assert np.array_equal(ctx.forward_y(frames[0]), want[0])
         assert ctx.fixup_stats()["exact_reruns"] == before
+
+
+@pytest.mark.parametrize("w,h,n", [(300, 203, 3), (1000, 97, 4), (2050, 333, 5)])
+def test_strict_rerun_of_stripes_with_any_row_count(weights_blob, w, h, n):
+    """The exact re-run of a row range (rerun_exact_rows): its layer-3 kernel walks 4-row tiles, so a range whose height is no
+    multiple of 4 has a last tile that reaches past the rows produced -- and past the map rows the re-run holds.  Fresh context
+    (the workspace is sized by the first re-run), stripes of 67 / 68 rows etc., halo rows in buffers of their own: the
+    reference's bytes, no out-of-bounds read (a soak faulted here before the window rows were clamped to the map's)."""
+    import torch
+    y = synth_luma(w, h, frame=6)
+    want = oracle.forward_y(y, weights_blob)[0]
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        ctx.set_mode(S.MODE_REFBYTES)
+        ctx.set_fixup_margin(0.25)
+        ctx.set_fixup_strict(True)
+        out = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
+        keep = []
+        for k in range(n):
+            r0, r1 = S.stripe_rows(h, n, k)
+            own = torch.from_numpy(np.ascontiguousarray(y[r0:r1])).cuda()
+            top = torch.from_numpy(np.ascontiguousarray(y[r0 - 6:r0])).cuda() if k > 0 else None
+            bot = torch.from_numpy(np.ascontiguousarray(y[r1:r1 + 6])).cuda() if k < n - 1 else None
+            keep += [own, top, bot]
+            torch.cuda.synchronize()
+            ctx.forward_y_rows_halo_dev(own.data_ptr(), w, r0, r1 - r0, top.data_ptr() if top is not None else 0,
+                                        bot.data_ptr() if bot is not None else 0, w, out.data_ptr(), w, 0, w, h, r0, r1)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        assert ctx.fixup_stats()["exact_reruns"] >= 1
