@@ -69,8 +69,8 @@ int srcnn_create(srcnn_ctx **out, int device)
     if (!c) return SRCNN_ERR_NOMEM;
     c->device = device;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipSetDevice(device) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    DeviceScope dev_scope_(c);           // like every entry point: the caller's current device is put back on return
+    if (dev_scope_.rc != SRCNN_OK || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return SRCNN_ERR_HIP;
     }
