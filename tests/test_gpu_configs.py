@@ -124,8 +124,10 @@ def test_batch_launch_forms_equal_single_plane(gpu_ctx, weights_blob, n_frames):
 def test_config3_7680x4320_as_8_stripes_of_540_rows(weights_blob):
     """configs[3] at size and in ITS partition: the 7680x4320 plane (3840x2160 x2.0) as 8 row stripes of 540 rows --
     (a) every stripe through srcnn_forward_y_rows_dev from exactly the rows a rank would hold (its own 540 + 6 halo rows
-    per interior side), (b) the whole step through srcnn_forward_y_striped_dev with 8 contexts on cuda:0 (halo copies
-    device to device, interior rows first, two edge bands per context).  Both must reproduce the sha256 the CPU model of
+    per interior side), (b) the whole step through srcnn_forward_y_striped_dev with 8 contexts on cuda:0 (ONE launch per
+    context, the neighbours' edge rows read where they lie), (c) every stripe through srcnn_forward_y_rows_halo_dev from its
+    own 540 rows and two separately allocated 6-row halo buffers -- what a rank of a one-process-per-GPU job launches.  All
+    must reproduce the sha256 the CPU model of
     the kernels' arithmetic gave in the build container, plane and stripe by stripe; two stripe EDGES (rows either side
     of a cut, where a halo error would show) are compared with the reference arithmetic."""
     import torch
@@ -156,13 +158,26 @@ def test_config3_7680x4320_as_8_stripes_of_540_rows(weights_blob):
         d_ins = [torch.from_numpy(np.ascontiguousarray(y[a:b])).cuda() for a, b in bounds]
         d_outs = [torch.zeros((b - a, w), dtype=torch.uint8, device="cuda") for a, b in bounds]
         torch.cuda.synchronize()
-        for _ in range(2):                                   # twice: the second step waits for the first one's band launches
+        for _ in range(2):                                   # twice, queued back to back
             S.forward_y_striped_dev(ctxs, [t.data_ptr() for t in d_ins], w, [t.data_ptr() for t in d_outs], w, w, h)
         for c in ctxs:
             c.synchronize()
         out_b = np.concatenate([t.cpu().numpy() for t in d_outs], axis=0)
         assert shas([out_b[a:b] for a, b in bounds]) == pin["stripe_gpuorder_sha256"]
         assert shas([out_b]) == pin["gpuorder_sha256"]
+        # (c) a rank's one launch: own rows + 6-row halo buffers of their own
+        out_c = np.empty_like(y)
+        for k, (r0, r1) in enumerate(bounds):
+            top = torch.from_numpy(np.ascontiguousarray(y[r0 - 6:r0])).cuda() if k > 0 else None
+            bot = torch.from_numpy(np.ascontiguousarray(y[r1:r1 + 6])).cuda() if k < n - 1 else None
+            d_out = torch.zeros((r1 - r0, w), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ctxs[k].forward_y_rows_halo_dev(d_ins[k].data_ptr(), w, r0, r1 - r0, top.data_ptr() if top is not None else 0,
+                                            bot.data_ptr() if bot is not None else 0, w, d_out.data_ptr(), w, r0, w, h, r0, r1)
+            ctxs[k].synchronize()
+            out_c[r0:r1] = d_out.cpu().numpy()
+        assert shas([out_c[a:b] for a, b in bounds]) == pin["stripe_gpuorder_sha256"]
+        assert shas([out_c]) == pin["gpuorder_sha256"]
         # reference arithmetic around two cuts: rows [cut - 40, cut + 40) -- the oracle on a crop is exact >= 6 rows from its ends
         for cut in (bounds[1][0], bounds[5][0]):
             a, b = cut - 46, cut + 46
