@@ -249,6 +249,10 @@ def parse_args():
                          "0 disables it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive secondary figure (`e2e`)")
+    ap.add_argument("--sustained-s", type=float, default=6.0,
+                    help="N = 1, fused path: after the timed region, keep running the same step for this many seconds and report the "
+                         "rate over it (`sustained`): the K timed steps are 20-50 ms of load, this is what the device holds for "
+                         "seconds (clocks, temperature).  0 skips it; so does --no-cpu-baseline (a quick run).")
     ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -618,6 +622,24 @@ def worker(args):
                                     "executed_mfma_flop_per_pixel": 43008,
                                     "executed_frac": round(achieved * 43008 / S.FLOP_PER_PIXEL / peak16, 4),
                                     "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)})
+        if world == 1 and args.path == "fused" and not stripe and args.sustained_s > 0 and not args.no_cpu_baseline:     # (--no-cpu-baseline marks a quick run)
+            # The timed region is K = 20-50 steps, 20-50 ms of load.  What the device sustains over SECONDS: the same step queued
+            # back to back in chunks of 200, every chunk between two events on the kernels' stream.
+            chunk, per_chunk, t_s = 200, [], time.perf_counter()
+            while time.perf_counter() - t_s < args.sustained_s:
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(stream)
+                for _ in range(chunk):
+                    step()
+                eb.record(stream)
+                eb.synchronize()
+                per_chunk.append(ea.elapsed_time(eb) / chunk)
+            ms_s = sum(per_chunk) / len(per_chunk)
+            out["sustained"] = {"seconds": round(time.perf_counter() - t_s, 2), "steps": chunk * len(per_chunk),
+                                "ms_per_step": round(ms_s, 4), "value": round(W * H * F / ms_s / 1e3, 2), "unit": "MPix/s",
+                                "frac": round(S.FLOP_PER_PIXEL * W * H * F / (ms_s * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                "slowest_chunk_ms_per_step": round(max(per_chunk), 4), "fastest_chunk_ms_per_step": round(min(per_chunk), 4),
+                                "what": f"the same step back to back for {args.sustained_s:g} s in chunks of {chunk}, HIP events per chunk; never `value`"}
         if world == 1 and args.path == "fused" and not stripe and not args.no_e2e:
             # SURVEY 8d's secondary metric, never `value`: the same planes from and to HOST memory, PCIe-inclusive
             # (srcnn_forward_y_frames: pinned staging, uploads / kernels / downloads of neighbouring frames overlapped).
