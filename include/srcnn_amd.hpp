@@ -86,6 +86,16 @@ public:
         thread_local Session s(0);
         return s;
     }
+    // The reference's BYTES from the MFMA path (SRCNN_MODE_REFBYTES, srcnn_amd.h): `strict` makes the library act on its own
+    // monitor -- a launch whose measured rounding noise comes within a factor two of the flag threshold is redone on the
+    // exact kernels -- at the price of one host synchronisation per launch.
+    void reference_bytes(bool on = true, bool strict = false)
+    {
+        check(srcnn_set_mode(get(), on ? SRCNN_MODE_REFBYTES : SRCNN_MODE_MFMA));
+        check(srcnn_set_fixup_strict(get(), strict ? 1 : 0));
+    }
+    // 0: the fast strip kernels (their hardware interlock was verified on this device at creation), 1: the hazard-safe ones
+    int kernel_variant() const { return srcnn_kernel_variant(get()); }
 
 private:
     struct Handle {
