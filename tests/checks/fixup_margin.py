@@ -3,7 +3,7 @@
 arithmetic, oracle/srcnn_gpuorder.c, is bitwise the GPU; oracle/srcnn_oracle.c is the reference arithmetic.)
 Prints, per content class, max / quantiles of |v_gpu - v_ref| over the pixels whose value can still change a byte
 (0.5 < v < 255.5), and how many pixels a fix-up threshold delta would flag.  This is what SRCNN_MODE_REFBYTES' delta
-(srcnn_api.cpp: kFixupDelta) is chosen from: profiles/r03/fixup_margin.txt.
+(srcnn_model.cpp: fixup_delta()) is chosen from: profiles/r03/fixup_margin.txt.
 usage: fixup_margin.py [megapixels per class]"""
 import sys
 from pathlib import Path

@@ -99,7 +99,7 @@ def test_config4_5760x3240_frame_stream(gpu_ctx, weights_blob):
 
 @pytest.mark.parametrize("n_frames", [3, 20])
 def test_batch_launch_forms_equal_single_plane(gpu_ctx, weights_blob, n_frames):
-    """How a batch is launched depends on its size (csrc/srcnn_api.cpp): a few large planes run as one single-plane launch
+    """How a batch is launched depends on its size (csrc/srcnn_plan.cpp, frames_per_launch): a few large planes run as one single-plane launch
     per frame, 17-31 of them as ONE launch that repeats the plane's work items -- row seams, column seams, the merged seam
     kernel over all frames -- frame after frame, larger batches on the regular grid.  Whatever the form, every frame must
     come out as it does launched alone (which the other tests pin to the model of the kernels' arithmetic)."""

@@ -379,7 +379,7 @@ def test_row_ranges_of_every_alignment(gpu_ctx, weights_blob, w, h):
 def test_single_plane_work_items_equal_batch_grid(gpu_ctx, weights_blob, w, h):
     """Launch-geometry independence at full sizes: a plane launched alone is cut into
     unequal per-block work items sized for the wave slot they land in
-    (csrc/srcnn_api.cpp plan_items); inside a batch the same plane runs on the regular
+    (csrc/srcnn_plan.cpp plan_items); inside a batch the same plane runs on the regular
     strip x segment grid.  Both must give the same bytes -- any gap or overlap in the item
     table shows up here.  A row stripe of the plane (row_begin != 0) is checked too."""
     torch = _torch()

@@ -87,7 +87,7 @@ def test_items_tile_every_strip_exactly(n_cu, n_strips, r0, r1, per_cu, seams):
 
 
 def finish_estimate(fast_rows, slow_rows, kf=6.40, ks=8.40, ka=3.76, sf=3.63, ss=5.44):
-    """The planner's model (cu_finish_estimate in srcnn_api.cpp; constants fitted to stamped launches,
+    """The planner's model (cu_finish_estimate in srcnn_plan.cpp; constants fitted to stamped launches,
     profiles/r03/planner_fit.txt): us until a CU has finished both of its items -- paired they take kf / ks us per row, the one
     left alone ka."""
     tf, ts = sf + fast_rows * kf, ss + slow_rows * ks

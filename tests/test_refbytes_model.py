@@ -13,7 +13,7 @@ from srcnn_cpp_amd.synth import synth_luma
 
 
 def shipped_delta(blob):
-    """fixup_delta() of srcnn_api.cpp: 6 * 2^-24 * ||W3||_2 * (rigorous bound of the layer-2 map for any 8-bit input), plus
+    """fixup_delta() of srcnn_model.cpp: 6 * 2^-24 * ||W3||_2 * (rigorous bound of the layer-2 map for any 8-bit input), plus
     4 * 2^-24 * 256 for the roundings at the output's own magnitude (the b3 additions)."""
     w1, b1, w2, b2, w3, _ = S.split_weights(blob)
     w1, w2, w3 = np.asarray(w1, np.float64).reshape(64, 81), np.asarray(w2, np.float64).reshape(32, 64), np.asarray(w3, np.float64)

@@ -86,7 +86,7 @@ def test_split16_arithmetic_matches_reference_arithmetic(ftz):
 
 
 def test_split16_ranges_hold_for_any_8bit_input():
-    """Rigorous bounds behind the f16 ranges (split16_range_ok() in csrc/srcnn_api.cpp)."""
+    """Rigorous bounds behind the f16 ranges (split16_range_ok() in csrc/srcnn_model.cpp)."""
     w1, b1, w2, b2, w3, _ = S.split_weights(S.load_weights())
     a1 = np.maximum(255.0 * np.maximum(w1.reshape(64, 81), 0).sum(1) + b1, 0)
     a2 = (np.maximum(w2, 0) * a1[None, :]).sum(1) + b2
