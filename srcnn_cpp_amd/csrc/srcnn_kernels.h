@@ -1,4 +1,4 @@
-// Internal interface between the C-ABI layer (srcnn_api.cpp) and the HIP
+// Internal interface between the C-ABI layer (srcnn_api.cpp and its sibling units, see srcnn_ctx.h) and the HIP
 // kernels.  Not installed; the public boundary is include/srcnn_amd.h.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -184,7 +184,7 @@ hipError_t launch_seams(const StripParams &p, int n_seams, const int *d_seams, h
 // completes those pixels -- same additions in the same order, bit-identical.
 constexpr int CSEAM_FLOATS = 16;      // 15 used
 hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream);
-// both in one launch; `winmap` [strips_total][rows] marks the rows inside a seam window of a strip (srcnn_api.cpp, plan_items_balanced())
+// both in one launch; `winmap` [strips_total][rows] marks the rows inside a seam window of a strip (srcnn_plan.cpp, plan_items_balanced())
 hipError_t launch_seams_merged(const StripParams &p, int n_seams, const int *d_seams, const unsigned char *d_winmap, int n_frames,
                                hipStream_t stream);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
