@@ -267,6 +267,10 @@ def parse_args():
                          "cxx: ONE process drives --gpus contexts through the C ABI's several-GPUs entry points "
                          "(srcnn_forward_y_striped_dev: hipMemcpyPeerAsync halo copies, persistent host threads; frames: one "
                          "context per GPU, launches queued from one host thread) -- the second transport of the scaling curve")
+    ap.add_argument("--fix-margin", type=float, default=None,
+                    help="REFBYTES modes: factor of the flag threshold's weight-proportional term (srcnn_set_fixup_margin; library default 4)")
+    ap.add_argument("--no-fix-strict", action="store_true",
+                    help="REFBYTES modes: drop the device-side safety net (srcnn_set_fixup_strict(0): no fix_rerun_kernel launch)")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)        # another build of the library (tools/ab.sh, the tuning build)
     ap.add_argument("--plpad", type=int, default=0, help=argparse.SUPPRESS)   # experiment: floats added to the unfused workspace's plane pitch (tuning build)
     ap.add_argument("--fault-rank", type=int, default=-1, help=argparse.SUPPRESS)      # test hook: this rank exits 7 before the rendezvous
@@ -340,6 +344,10 @@ def worker(args):
         ctx.set_mode(S.MODE_REFBYTES)
     elif args.mode == "refbytes16":                                # opt-in: split-f16 kernel + exact fix-up
         ctx.set_mode(S.MODE_REFBYTES16)
+    if args.fix_margin is not None:
+        ctx.set_fixup_margin(args.fix_margin)
+    if args.no_fix_strict:
+        ctx.set_fixup_strict(False)
     # a real (non-null) stream that both torch's events and the HIP kernels use
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
@@ -609,9 +617,9 @@ def worker(args):
             out["dtype"] = "f16x2-split operands, f32 accumulate + exact f32 recomputation of flagged pixels"
             out["roofline"].update({"peak": PEAK_F16_MFMA_TFLOPS, "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
                                     "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                                    "note": "strip kernel on f16 MFMAs + fix_collect / fix_apply on the vector ALU in one figure"})
+                                    "note": "strip kernel on f16 MFMAs + fix_apply on the vector ALU in one figure"})
         if args.mode == "refbytes":
-            out["roofline"]["note"] = ("the step is the f32-MFMA strip kernel (its own frac: --mode mfma) plus fix_collect / fix_apply "
+            out["roofline"]["note"] = ("the step is the f32-MFMA strip kernel (its own frac: --mode mfma) plus fix_apply (+ the idle fix_rerun launch) "
                                        "on the vector ALU; frac here is the algorithmic rate of the whole step over the f32-MFMA peak")
         if args.mode == "split16":
             # opt-in mode: priced against the dense f16 MFMA peak with the same ALGORITHMIC flops; the

@@ -73,13 +73,15 @@ enum {
  *   SRCNN_MODE_REFBYTES the reference's BYTES at nearly the MFMA speed: the fused forward pass
  *                    (srcnn_forward_y*, row stripes, srcnn_process_bgr*) runs the float32 MFMA kernel, which
  *                    also marks every pixel whose pre-truncation value lies within delta of an
- *                    integer (~0.4 % of them; delta is derived from the model), and
+ *                    integer (~0.3 % of them; delta is derived from the model), and
  *                    exactly those pixels are then recomputed in the reference's arithmetic
  *                    (src/srcnn.cpp:238-240 truncates: only there can rounding noise change a byte).
+ *                    The recomputation measures how far the MFMA values were off; a launch where that
+ *                    exceeds delta / 2 is redone in the reference's arithmetic on EVERY pixel, on the
+ *                    device, without a host read (srcnn_set_fixup_strict, on by default).
  *                    Output: bit-identical to the reference CPU path on every input tried, adversarially
- *                    searched ones included; the guarantee is conditional on the monitored margin
- *                    (srcnn_fixup_stats, srcnn_set_fixup_strict).  The per-filter entry points and
- *                    the materialising path run as in MFMA mode; a pre-clamp request runs the
+ *                    searched ones included (srcnn_fixup_stats reports the margin).  The per-filter entry
+ *                    points and the materialising path run as in MFMA mode; a pre-clamp request runs the
  *                    exact kernels.
  *   SRCNN_MODE_REFBYTES16 opt-in, like SPLIT16 outside the float32 north star: the same flag-and-recompute
  *                    scheme behind the split-f16 kernel (threshold 8/6 of REFBYTES': that kernel's noise is a
@@ -330,20 +332,24 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 
 /* SRCNN_MODE_REFBYTES: counters accumulated over the context's launches in that mode since creation (64-bit on the device).
  * out[0] = pixels flagged and recomputed one by one, out[1] = 12x12 tiles recomputed whole (flat / periodic
- * content), out[2] = bytes the recomputation changed, out[3] = launches redone on the exact kernels in strict mode;
+ * content), out[2] = bytes the recomputation changed, out[3] = fix-ups (a launch, or the <= 16 frames of a batch that share
+ * one) redone in the reference's arithmetic on every pixel because their monitored deviation exceeded delta / 2;
  * *delta = the flag threshold of the loaded model, *max_dev = the largest |v_mfma - v_reference| met on a
- * flagged pixel (a random ~0.4 % sample of all pixels).  Synchronises the stream.
+ * flagged pixel (a random ~0.3 % sample of all pixels).  Synchronises the stream.
  *
  * WHAT THE MODE GUARANTEES.  Its bytes are the reference's wherever |v_mfma - v_reference| <= delta.  delta is not a proven
- * bound of that rounding noise (the rigorous one is ~10 grey levels): it is 6 x the noise scale of the loaded model,
- * 4.6 x the largest deviation met on 54 MPix of content and 3.2 x the largest an adversarial search over receptive fields
- * found (profiles/r04/fixup_adversarial.txt: 0.32 delta for the shipped model, <= 0.35 delta over 24 random models).  So the
- * guarantee is CONDITIONAL on max_dev < delta, which the library lets a deployment watch and act on:
- *   srcnn_set_fixup_strict(ctx, 1)  after every fix-up the host reads that launch's max_dev; above delta / 2 the launch's
- *                                   frames are redone on the exact kernels (SRCNN_MODE_EXACT arithmetic on every pixel) and
- *                                   counted in out[3].  One host synchronisation per fix-up (per <= 16 frames of a batch).
- *   srcnn_set_fixup_margin(ctx, k)  delta = k x (noise scale) + the absolute term; default 6, range [0.25, 64].  The
- *                                   fix-up's cost is linear in it (~0.12 ms per 1e-3 of delta on a 3840x2160 plane). */
+ * bound of that rounding noise (the rigorous one is ~10 grey levels): it is 4 x the noise scale of the loaded model (+ an
+ * absolute term), 3.1 x the largest deviation met on 54 MPix of content and 2.1 x the largest an adversarial search over
+ * receptive fields found (profiles/r04/fixup_adversarial.txt: 6.4e-4 = 0.47 delta for the shipped model).  So the guarantee is
+ * CONDITIONAL on max_dev < delta, and the library ACTS on the condition:
+ *   srcnn_set_fixup_strict(ctx, on) ON BY DEFAULT.  A kernel queued behind the recomputation unconditionally compares the
+ *                                   launch's max_dev with delta / 2 and, when it is exceeded, redoes the launch's rows in the
+ *                                   reference's arithmetic on every pixel (counted in out[3]).  All on the device: no host
+ *                                   read, a queued stream of frames is never stalled; ~2 us per fix-up when nothing is to be
+ *                                   redone, ~3 x SRCNN_MODE_EXACT's time for a launch that is.  0 drops that kernel (the
+ *                                   monitor still reports).
+ *   srcnn_set_fixup_margin(ctx, k)  delta = k x (noise scale) + the absolute term; default 4 (rounds 3-4: 6), range
+ *                                   [0.25, 64].  The fix-up's cost is linear in it. */
 int srcnn_fixup_stats(srcnn_ctx *ctx, unsigned long long out[4], float *delta, float *max_dev);
 int srcnn_set_fixup_strict(srcnn_ctx *ctx, int on);
 int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);

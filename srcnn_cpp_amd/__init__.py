@@ -332,11 +332,12 @@ class Context:
                 "exact_reruns": int(out[3]), "delta": float(delta.value), "max_dev": float(dev.value)}
 
     def set_fixup_strict(self, on: bool = True):
-        """SRCNN_MODE_REFBYTES: redo a launch on the exact kernels when its monitored deviation exceeds delta / 2."""
+        """SRCNN_MODE_REFBYTES: redo a launch in the reference's arithmetic on every pixel when its monitored deviation exceeds
+        delta / 2 -- on the device, no host read; ON by default."""
         self._check(self._lib.srcnn_set_fixup_strict(self._h, int(bool(on))))
 
     def set_fixup_margin(self, factor: float):
-        """SRCNN_MODE_REFBYTES: delta = factor x (noise scale of the model) + absolute term; default 6."""
+        """SRCNN_MODE_REFBYTES: delta = factor x (noise scale of the model) + absolute term; default 4."""
         self._check(self._lib.srcnn_set_fixup_margin(self._h, float(factor)))
 
     # the two reference calls with the 32-plane map kept in device memory between them (include/srcnn_amd.h)

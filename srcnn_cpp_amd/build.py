@@ -61,7 +61,8 @@ def kernel_sources_fingerprint() -> str:
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in ("srcnn_mfma.hip", "srcnn_split16.hip", "srcnn_kernels.h", "srcnn_ctx.h", "srcnn_plan.cpp", "srcnn_launch.cpp"):
+    for name in ("srcnn_mfma.hip", "srcnn_split16.hip", "srcnn_exact.hip", "srcnn_probe.hip", "srcnn_kernels.h", "srcnn_ctx.h",
+                 "srcnn_model.cpp", "srcnn_plan.cpp", "srcnn_launch.cpp"):
         text = (CSRC / name).read_text()
         # the CODE, not its commentary: comments removed (no string literal of these files holds "//" or "/*"), white space collapsed
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)

@@ -185,7 +185,7 @@ int srcnn_fixup_stats(srcnn_ctx *c, unsigned long long out[4], float *delta, flo
     out[0] = t[FIX_N_SCAT];
     out[1] = t[FIX_N_DENSE];
     out[2] = t[FIX_N_CHANGED];
-    out[3] = c->fix_reruns;
+    out[3] = t[FIX_N_RERUN];
     if (delta) *delta = c->mode == SRCNN_MODE_REFBYTES16 ? c->fix_delta * (8.f / 6.f) : c->fix_delta;
     if (max_dev) {
         const unsigned bits = (unsigned)t[FIX_MAX_DEV];

@@ -129,6 +129,9 @@ public:
 }  // namespace host
 }  // namespace srcnn
 
+// SRCNN_MODE_REFBYTES: default factor of the flag threshold's weight-proportional term (fixup_delta(), srcnn_set_fixup_margin)
+constexpr float kFixMargin = 4.f;
+
 struct srcnn_ctx {
     int device = 0;
     int n_cu = 256;
@@ -203,9 +206,8 @@ struct srcnn_ctx {
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
     size_t pin_cap = 0;
     float fix_delta = 0.f;                 // SRCNN_MODE_REFBYTES: flag threshold for the uploaded model (fixup_delta())
-    float fix_margin = 6.f;                // ... the factor of its weight-proportional term (srcnn_set_fixup_margin)
-    bool fix_strict = false;               // ... act on the monitor: a launch whose max_dev > delta / 2 is redone on the exact kernels
-    unsigned long long fix_reruns = 0;     // ... how many launches that happened to (srcnn_fixup_stats out[3])
+    float fix_margin = kFixMargin;         // ... the factor of its weight-proportional term (srcnn_set_fixup_margin)
+    bool fix_strict = true;                // ... act on the monitor: a launch whose max_dev > delta / 2 is redone in the reference's arithmetic (fix_rerun_kernel)
     srcnn::host::DevBuf fix_totals;                     // ... and its counters accumulated over the context's launches (srcnn_fixup_stats)
     std::unique_ptr<srcnn::host::WorkerPool> pool;      // host threads of the several-GPUs calls this context leads (WorkerPool)
 };
@@ -255,7 +257,7 @@ void release(DevBuf &b);
 constexpr int kHaloRows = 6;   // 4 input rows of the 9x9 layer + 2 feature rows of the 5x5 layer
 
 // ---- srcnn_model.cpp ----
-float fixup_delta(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, double margin = 6.0);
+float fixup_delta(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, double margin = kFixMargin);
 void pack_fragments(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, float *out);
 void pack_fragments16(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3, uint8_t *out);
 bool split16_range_ok(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3);

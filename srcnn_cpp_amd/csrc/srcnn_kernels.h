@@ -109,13 +109,17 @@ struct StripParams {
 };
 
 // ---- SRCNN_MODE_REFBYTES: fix-up of the pixels whose MFMA value lies within delta of a truncation boundary (srcnn_exact.hip)
-// Per-launch counter words (zeroed by the strip kernel) and the context's running totals (words 0 .. FIX_TOTALS - 1 of another
-// buffer).  The work lists are filled in FIX_REGIONS regions, each with its own pair of reservation words 256 B apart: a
-// returning atomic on ONE word sustains ~88 per microsecond chip-wide, and fix_collect_kernel makes one reservation per
-// workgroup -- 900 of them on a 3840x2160 plane (one word: 16.3 us for the kernel, eight: 8.0).
-enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_NEXT_ITEM = 4, FIX_TOTALS = 5,
-       FIX_REGIONS = 8, FIX_REGION_WORDS = 64, FIX_REGION0 = 64,      // region r: [FIX_REGION0 + r * FIX_REGION_WORDS] scattered pixels, [+ 32] dense tiles
-       FIX_COUNTERS = FIX_REGION0 + FIX_REGIONS * FIX_REGION_WORDS };
+// Per-launch counter words (zeroed by the strip kernel), FIX_WORD_STRIDE words = 256 B apart so that atomics on different counters
+// do not queue on one line, and the context's running totals (FIX_TOTALS 64-bit words of another buffer).  The work lists are filled in FIX_REGIONS regions, each
+// with its own pair of reservation words: a returning atomic on ONE word sustains ~88 per microsecond chip-wide, and
+// fix_collect_kernel makes one reservation per workgroup -- 900 of them on a 3840x2160 plane (one word: 16.3 us for the kernel,
+// eight: 8.0).
+enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_N_RERUN = 4, FIX_TOTALS = 5,
+       FIX_WORD_STRIDE = 64,
+       FIX_NEXT_ITEM = 5,    // item draw of fix_apply_kernel
+       FIX_NEXT_RERUN = 6,   // tile draw of fix_rerun_kernel
+       FIX_REGIONS = 8, FIX_REGION0 = 7 * FIX_WORD_STRIDE,      // region r: [FIX_REGION0 + r * FIX_WORD_STRIDE] scattered pixels, [+ 32] dense tiles
+       FIX_COUNTERS = FIX_REGION0 + FIX_REGIONS * FIX_WORD_STRIDE };
 struct FixParams {
     const uint8_t *src;             // the launch's Y input, as the strip kernel reads it
     long src_stride;
@@ -129,10 +133,14 @@ struct FixParams {
     int dst_row0;
     int width, height, row_begin, row_end;
     const float *wraw;              // b1|W1|b2|W2|b3|W3 in convdata.h order, then W2 transposed [64][32], then W1 transposed [81][64]
-    unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel
-    unsigned long long *totals;     // the same four as 64-bit words, accumulated over every launch of the context (srcnn_fixup_stats)
+    unsigned *counters;             // FIX_COUNTERS words, zeroed by the strip kernel; counter k at counters[k * FIX_WORD_STRIDE]
+    unsigned long long *totals;     // FIX_TOTALS 64-bit words, accumulated over every launch of the context (srcnn_fixup_stats)
     unsigned *scat, *dense;         // work lists in FIX_REGIONS equal regions: pixel (frame * height + y) * width + x; tile index
     float delta, code_step;         // code_step = 2 delta / 253
+    // The monitor ACTS, on the device: fix_rerun_kernel, queued behind fix_apply_kernel unconditionally, compares the launch's largest
+    // |v_mfma - v_reference| with rerun_above (delta / 2; negative = always: the test hook) and recomputes every pixel of the
+    // launch in the reference's arithmetic when it is exceeded.
+    float rerun_above;
     // one fix-up for the planes of several single-frame strip launches (srcnn_forward_y_dev): frame k of the batch lies at
     // src + k * src_frame_pitch / dst + k * dst_frame_pitch / flag + k * flag_frame_pitch, same rows in every frame
     int n_frames;
@@ -159,7 +167,8 @@ __device__ __forceinline__ uint8_t fix_src_at(const FixParams &p, int frame, int
     return p.src[(long)frame * p.src_frame_pitch + (long)(yy - p.src_row0) * p.src_stride + xx];
 }
 
-hipError_t launch_fixup(const FixParams &p, int n_cu, hipStream_t st);
+// fix_collect_kernel, fix_apply_kernel, and behind them fix_rerun_kernel when `with_rerun` (srcnn_set_fixup_strict, the default)
+hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, hipStream_t st);
 constexpr int FIX_BATCH_FRAMES = 16;      // frames per fix-up launch at most (pixel codes stay below 2^32 up to 16 x 16384 x 16384)
 size_t fixup_list_entries(int width, int rows, int n_frames, size_t *dense_entries);
 
@@ -205,11 +214,6 @@ hipError_t launch_conv11_exact(const float *planes, long stride, long pitch, flo
 hipError_t launch_conv99x11_exact(const uint8_t *src, long sstride, long src_frame_pitch,
                                   float *planes, long stride, long pitch, long frame_pitch,
                                   int w, int h, int n_frames, const float *d_weights, hipStream_t st);
-hipError_t launch_conv99x11_exact_rows(const uint8_t *src, long sstride, int src_row0, float *planes, long stride, long pitch,
-                                       int pl_row0, int w, int h, int row0, int row1, const float *d_weights, hipStream_t st);
-hipError_t launch_conv55_exact_rows(const float *planes, long stride, long pitch, int pl_row0, int pl_row1, uint8_t *dst, long dstride,
-                                    int dst_row0, int w, int h, int row0, int row1, const float *d_kernel800, float bias,
-                                    hipStream_t st);
 hipError_t launch_conv55_exact(const float *planes, long stride, long pitch, long frame_pitch,
                                uint8_t *dst, float *pre, long dstride, long dst_frame_pitch,
                                int w, int h, int n_frames, const float *d_kernel800, float bias,

@@ -217,7 +217,9 @@ class StripeStep:
     no tensor construction per step (at 8 GPUs a 7680x4320 step is 0.47 ms of kernel per rank).
 
     stripe / out : uint8 tensors [r1-r0, W], this rank's rows of the input / output plane; the SAME tensors
-                   every step (refill ``stripe`` in place for a new plane).  ``stripe`` must be contiguous: its
+                   every step.  For a new plane refill ``stripe`` in place on the CURRENT stream and call ``refilled()``:
+                   in the one-launch form the exchange runs on a side stream, which must be ordered behind the refill
+                   (the other forms post on the current stream and need nothing).  ``stripe`` must be contiguous: its
                    first / last 6 rows are sent as they lie.
     launch_rows_halo : given, the step is ONE launch on the stripe where it lies with the received halo rows in two small
                    tensors of their own (``gpu_launch_rows_halo``; the float32 MFMA kernel picks the buffer a row lives in).
@@ -240,6 +242,7 @@ class StripeStep:
         self.stripe, self.out, self.height, self.world, self.rank = stripe, out, height, world, rank
         self.launch_rows, self.group, self.via_host = launch_rows, group, via_host
         self.launch_rows_halo, self.n_steps = launch_rows_halo, 0
+        self._refill = None            # event behind the stripe's last write, consumed by the next exchange (refilled())
         self.r0, self.r1 = stripe_rows(height, world, rank)
         if stripe.shape[0] != self.r1 - self.r0 or out.shape != stripe.shape:
             raise ValueError(f"rank {rank}: stripe has {stripe.shape[0]} rows, owns [{self.r0},{self.r1})")
@@ -346,6 +349,14 @@ class StripeStep:
             self.launch_rows(self.bot_buf, r1 - 2 * HALO_ROWS, out, r0, h, bot[0], bot[1])
         return out
 
+    def refilled(self):
+        """Call after writing a NEW plane's rows into ``stripe`` on the current stream: the next step's exchange, which
+        sends the stripe's edge rows from a side stream, waits for those writes (once; steps on an unchanged stripe stay
+        unserialised).  The kernels of earlier steps that still read the stripe are ordered by the stream itself."""
+        import torch
+        if self.stripe.is_cuda:
+            self._refill = torch.cuda.current_stream().record_event()
+
     def _step_halo(self):
         """ONE launch: exchange into this step's halo set, then the whole stripe (see the class docstring)."""
         import torch
@@ -356,6 +367,9 @@ class StripeStep:
         for view, host in st["send_stage"]:
             host.copy_(view)
         if self.side is not None:
+            if self._refill is not None:           # the edge rows about to be sent were written on the current stream
+                self.side.wait_event(self._refill)
+                self._refill = None
             # the exchange waits only for the launch that last read THIS set (HALO_SETS steps ago), not for the previous steps:
             # its kernels need a free compute unit and find one in the tail of an earlier step's launch (same-box timing,
             # tools/stripe_projection.py --diag: with two sets the hand-over cost 34 us per step, most of it this wait)
@@ -404,18 +418,34 @@ class PeerStripeStep:
         self.top = self.bot = 0
         self._mapped = []
         if world > 1:
+            # Collective-safe: a rank whose export / mapping fails (no IPC between these two devices, a runtime without dmabuf
+            # IPC) must not leave the others waiting in a collective -- every rank reports, then all succeed or all raise.
+            err, handle = None, None
+            try:
+                handle = ctx.ipc_export(self.d_stripe)
+            except Exception as e:          # noqa: BLE001 -- reported to every rank below
+                err = f"rank {rank}: export: {e}"
             handles = [None] * world
-            dist.all_gather_object(handles, ctx.ipc_export(self.d_stripe), group=group)
-            if rank > 0:
-                a0, a1 = stripe_rows(height, world, rank - 1)
-                base = ctx.ipc_open(handles[rank - 1])
-                self._mapped.append(base)
-                self.top = base + (a1 - a0 - HALO_ROWS) * self.width          # the upper neighbour's last 6 rows
-            if rank < world - 1:
-                base = ctx.ipc_open(handles[rank + 1])
-                self._mapped.append(base)
-                self.bot = base                                                # the lower neighbour's first 6 rows
-            dist.barrier(group=group)       # every stripe is uploaded before anybody's first step reads a neighbour's rows
+            dist.all_gather_object(handles, (handle, err), group=group)
+            if all(h[1] is None for h in handles):
+                try:
+                    if rank > 0:
+                        a0, a1 = stripe_rows(height, world, rank - 1)
+                        base = ctx.ipc_open(handles[rank - 1][0])
+                        self._mapped.append(base)
+                        self.top = base + (a1 - a0 - HALO_ROWS) * self.width          # the upper neighbour's last 6 rows
+                    if rank < world - 1:
+                        base = ctx.ipc_open(handles[rank + 1][0])
+                        self._mapped.append(base)
+                        self.bot = base                                                # the lower neighbour's first 6 rows
+                except Exception as e:      # noqa: BLE001
+                    err = f"rank {rank}: open: {e}"
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)     # (also: every stripe is uploaded before anybody's first step reads a neighbour's rows)
+            bad = [e for e in errs if e] + [h[1] for h in handles if h[1]]
+            if bad:
+                self.close(collective=False)
+                raise RuntimeError("HIP IPC mapping of the neighbours' stripes failed: " + "; ".join(sorted(set(bad))))
 
     def upload(self, stripe_rows_np):
         self.ctx.dev_upload(self.d_stripe, stripe_rows_np)
@@ -429,15 +459,16 @@ class PeerStripeStep:
 
     __call__ = step
 
-    def close(self):
+    def close(self, collective: bool = True):
         import torch.distributed as dist
         self.ctx.synchronize()
-        if self.world > 1:
+        collective = collective and self.world > 1
+        if collective:
             dist.barrier(group=self.group)  # nobody reads this rank's rows any more
         for base in self._mapped:
             self.ctx.ipc_close(base)
         self._mapped = []
-        if self.world > 1:
+        if collective:
             dist.barrier(group=self.group)  # every mapping of this rank's allocation is gone before it is freed
         if self.d_stripe:
             self.ctx.dev_free(self.d_stripe)

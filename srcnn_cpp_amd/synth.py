@@ -22,10 +22,10 @@ def _tri(t, p):
     return np.abs((t % (2 * p)) - p)
 
 
-def synth_luma(width: int, height: int, frame: int = 0, seed: int = DEFAULT_SEED) -> np.ndarray:
-    """One height x width uint8 plane for frame index `frame`."""
+def synth_luma(width: int, height: int, frame: int = 0, seed: int = DEFAULT_SEED, rows=None) -> np.ndarray:
+    """One height x width uint8 plane for frame index `frame`; rows = (r0, r1): only those rows of it (a rank's stripe)."""
     x = np.arange(width, dtype=np.int64)[None, :]
-    y = np.arange(height, dtype=np.int64)[:, None]
+    y = np.arange(*(rows if rows is not None else (0, height)), dtype=np.int64)[:, None]
     f = int(frame)
     idx = ((f * height + y) * width + x) & 0xFFFFFFFF
     h = (seed ^ idx) & 0xFFFFFFFF

@@ -75,8 +75,7 @@ while time.time() - t0 < budget:
             strict = mode == S.MODE_REFBYTES and rng.random() < 0.3
             note("halo stripes", w, h, ns, mode, strict)
             if strict:
-                ctx.set_fixup_margin(0.25)
-                ctx.set_fixup_strict(True)
+                ctx.set_fixup_margin(0.25)              # below the noise: the device-side re-run takes over (strict is the default)
             d_o = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
             keep = []
             for k in range(ns):
@@ -96,8 +95,7 @@ while time.time() - t0 < budget:
             want = m_out if mode == S.MODE_MFMA else r_out
             assert np.array_equal(d_o.cpu().numpy(), want), ("halo stripes", mode, strict, w, h, ns)
             if strict:
-                ctx.set_fixup_strict(False)
-                ctx.set_fixup_margin(6.0)
+                ctx.set_fixup_margin(4.0)
         ctx.set_mode(S.MODE_MFMA)
     # the two reference functions on device memory
     if w * h <= 4_500_000:

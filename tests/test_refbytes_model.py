@@ -12,14 +12,14 @@ import srcnn_cpp_amd as S
 from srcnn_cpp_amd.synth import synth_luma
 
 
-def shipped_delta(blob):
-    """fixup_delta() of srcnn_model.cpp: 6 * 2^-24 * ||W3||_2 * (rigorous bound of the layer-2 map for any 8-bit input), plus
+def shipped_delta(blob, margin=4.0):
+    """fixup_delta() of srcnn_model.cpp: margin (default 4; rounds 3-4: 6) * 2^-24 * ||W3||_2 * (rigorous bound of the layer-2 map for any 8-bit input), plus
     4 * 2^-24 * 256 for the roundings at the output's own magnitude (the b3 additions)."""
     w1, b1, w2, b2, w3, _ = S.split_weights(blob)
     w1, w2, w3 = np.asarray(w1, np.float64).reshape(64, 81), np.asarray(w2, np.float64).reshape(32, 64), np.asarray(w3, np.float64)
     a1 = np.maximum(0.0, 255.0 * np.maximum(w1, 0).sum(1) + np.asarray(b1, np.float64))
     m2 = (np.maximum(w2, 0) @ a1 + np.asarray(b2, np.float64)).max()
-    return 6.0 * 2.0 ** -24 * np.sqrt((w3 ** 2).sum()) * m2 + 4.0 * 2.0 ** -24 * 256.0
+    return margin * 2.0 ** -24 * np.sqrt((w3 ** 2).sum()) * m2 + 4.0 * 2.0 ** -24 * 256.0
 
 
 def planes():
@@ -34,7 +34,7 @@ def planes():
 
 
 def test_threshold_of_the_shipped_model(weights_blob):
-    assert abs(shipped_delta(weights_blob) - 2.033e-3) < 2e-6          # what srcnn_fixup_stats reports on the GPU
+    assert abs(shipped_delta(weights_blob) - 1.3759e-3) < 2e-6          # what srcnn_fixup_stats reports on the GPU
 
 
 @pytest.mark.parametrize("name,y", list(planes()), ids=[n for n, _ in planes()])
@@ -67,7 +67,7 @@ def test_model_with_small_weights_and_a_large_bias():
         w3 = (rng.standard_normal(800) * rng.uniform(0.005, 0.05)).astype(np.float32)
         blob = np.concatenate([b1, w1, b2, w2, [np.float32(rng.uniform(129, 250))], w3]).astype(np.float32)
         delta = shipped_delta(blob)
-        assert delta < 4e-4                                                # the absolute term is most of it
+        assert delta < 3e-4                                                # the absolute term is most of it
         y = rng.integers(0, 256, (160, 400), dtype=np.uint8)
         g_out, g_pre = oracle.gpuorder_forward_y(y, blob)
         r_out, r_pre = oracle.forward_y(y, blob)
