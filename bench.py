@@ -191,6 +191,135 @@ def launch_ranks(n: int, cmd=None) -> int:
     return failed[1] if 0 < failed[1] < 256 else 1
 
 
+# --------------------------------------------------------------------------- the row-striped plane riding on the frames line
+
+# One 7680x4320 plane on ONE MI355X, fused float32 MFMA path, resident in HBM: the denominator of the stripe leg's speed-up.
+# profiles/r04/measurements.jsonl (3.744 ms), re-measured in round 5 on three boxes (3.737-3.752 ms: profiles/r05/).
+N1_PLANE_MS = {"width": 7680, "height": 4320, "ms": 3.744, "source": "profiles/r04/measurements.jsonl, profiles/r05/fix_apply_ab*.txt (3.737-3.758 on five boxes)"}
+
+
+def stripe_leg(args, S, torch, dist, ctx, world, rank, timed, make_rccl):
+    """BASELINE configs[3] at N = world: the 7680x4320 plane row-striped over the ranks, every rank ONE launch per step on its own
+    rows (srcnn_forward_y_rows_halo_dev), in the transports that exist on this node -- `halo`: the 6 boundary rows travel by RCCL
+    send/recv every step (host-staged over gloo with --backend gloo: a smoke configuration, marked degraded); `peer`: no per-step
+    exchange, the neighbours' stripes are mapped once through HIP IPC and the kernel loads their edge rows where they lie (xGMI
+    between GPUs).  Per form: ms per image (first rank's start -> last rank's end over K steps), per-rank ms, speed-up against
+    the committed one-GPU time, and the sha256 of the stitched plane against tests/golden/config_checksums.json.  Collective:
+    every rank runs it; rank 0 returns the object."""
+    import hashlib
+    import numpy as np
+    from srcnn_cpp_amd import sharding
+    from srcnn_cpp_amd.synth import synth_luma
+
+    SW, SH = N1_PLANE_MS["width"], N1_PLANE_MS["height"]
+    if min(b - a for a, b in (sharding.stripe_rows(SH, world, k) for k in range(world))) < sharding.HALO_ROWS:
+        return {"skipped": f"{world} ranks leave stripes thinner than the 6-row halo"} if rank == 0 else None
+    try:
+        pin = json.loads((ROOT / "tests" / "golden" / "config_checksums.json").read_text())["c3_7680x4320"]["gpuorder_sha256"][0]
+    except Exception:                      # noqa: BLE001 -- the checksum file travels with the tree; say so if it does not
+        pin = None
+    r0, r1 = sharding.stripe_rows(SH, world, rank)
+    rows_np = synth_luma(SW, SH, rows=(r0, r1))
+    d_s = torch.from_numpy(rows_np).cuda()
+    d_o = torch.zeros_like(d_s)
+    rows = [sharding.stripe_rows(SH, world, k) for k in range(world)]
+    pad = max(b - a for a, b in rows)
+
+    def measure(step_fn):
+        for _ in range(32):                # the same COUNT on every rank (they exchange every step), untimed
+            step_fn()
+        torch.cuda.synchronize()
+        t_a, t_b, _, kern = timed(args.steps, step_fn)
+        t = torch.tensor([t_a, t_b, kern], dtype=torch.float64)
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        buf = torch.zeros((pad, SW), dtype=torch.uint8)
+        buf[: r1 - r0] = d_o.cpu()
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        if rank != 0:
+            return None
+        plane = torch.cat([p[: b - a] for p, (a, b) in zip(parts, rows)], dim=0).numpy()
+        sha = hashlib.sha256(np.ascontiguousarray(plane).tobytes()).hexdigest()
+        ms = float(max(x[1] for x in all_t) - min(x[0] for x in all_t)) / args.steps * 1e3
+        per_rank = [float(x[1] - x[0]) / args.steps * 1e3 for x in all_t]
+        return {"ms_per_image": round(ms, 4), "value": round(SW * SH / ms / 1e3, 2), "unit": "MPix/s",
+                "per_rank_ms": [round(v, 4) for v in per_rank], "per_rank_kernel_ms": [round(float(x[2]), 4) for x in all_t],
+                "per_rank_frac_of_f32_mfma_peak": [round(S.FLOP_PER_PIXEL * SW * (b - a) / (float(x[2]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                                                   for x, (a, b) in zip(all_t, rows)],
+                "speedup_vs_one_gpu": round(N1_PLANE_MS["ms"] / ms, 3), "output_sha256": sha,
+                "sha256_equals_golden": (sha == pin) if pin else None}
+
+    def agree(ok, why=""):
+        """every rank says whether its part of a set-up worked; all go on, or none does"""
+        said = [None] * world
+        dist.all_gather_object(said, None if ok else f"rank {rank}: {why}")
+        bad = [s for s in said if s]
+        return (not bad), "; ".join(bad)
+
+    out = {"workload": f"ONE {SW}x{SH} luma plane (BASELINE configs[3]) row-striped over {world} GPU(s), one launch per rank per step, "
+                       f"float32 MFMA path, stripes resident in HBM; {args.steps} timed steps behind 32 untimed ones",
+           "one_gpu_reference": N1_PLANE_MS, "golden_sha256": pin, "forms": {}}
+    degraded = []
+    # ---- halo: a 6-row exchange per step ----
+    rccl, rccl_world, why = None, None, ""
+    if args.backend == "nccl":
+        try:
+            rccl, rccl_world = make_rccl()
+        except Exception as e:             # noqa: BLE001
+            why = str(e)[:200]
+        ok, said = agree(rccl is not None, why)
+        if not ok:
+            rccl, rccl_world, why = None, None, said
+    try:
+        stepper = sharding.StripeStep(d_s, d_o, SH, world, rank, sharding.gpu_launch_rows(ctx), group=rccl, overlap=True,
+                                      via_host=rccl is None, launch_rows_halo=sharding.gpu_launch_rows_halo(ctx))
+        res = measure(stepper.step)
+        if rank == 0:
+            transport = "rccl send/recv" if rccl is not None else "host-staged (gloo)"
+            res.update({"halo_transport": transport, "rccl_world": rccl_world})
+            if rccl is None:
+                res["rccl_error"] = why or "--backend gloo"
+                degraded.append("halo: the 6-row exchange did not run over RCCL")
+            elif rccl_world != world:
+                degraded.append(f"halo: RCCL summed over {rccl_world} ranks")
+            if res["sha256_equals_golden"] is False:
+                degraded.append("halo: stitched plane differs from the golden checksum")
+            out["forms"]["halo"] = res
+    except Exception as e:                 # noqa: BLE001 -- a failed form must not take the frames line with it
+        if rank == 0:
+            out["forms"]["halo"] = {"error": str(e)[:300]}
+            degraded.append("halo: failed")
+    # ---- peer: the neighbours' stripes mapped once (HIP IPC), no exchange per step ----
+    d_o.zero_()
+    torch.cuda.synchronize()
+    peer = None
+    try:
+        peer = sharding.PeerStripeStep(ctx, rows_np, d_o, SH, world, rank, group=None)
+        err = ""
+    except Exception as e:                 # noqa: BLE001 (collective inside: every rank raises, or none)
+        err = str(e)[:300]
+    if peer is not None:
+        res = measure(peer.step)
+        peer.close()
+        if rank == 0:
+            res["halo_transport"] = ("none per step: the neighbours' stripes are mapped once (HIP IPC), the kernel loads their 6 edge "
+                                     "rows where they lie" + (" -- ALL RANKS ON ONE GPU (--shared-gpu): no xGMI link crossed" if args.shared_gpu else " (xGMI between GPUs)"))
+            if res["sha256_equals_golden"] is False:
+                degraded.append("peer: stitched plane differs from the golden checksum")
+            out["forms"]["peer"] = res
+    elif rank == 0:
+        out["forms"]["peer"] = {"error": err}
+        degraded.append("peer: HIP IPC mapping unavailable")
+    if args.shared_gpu:
+        degraded.append("--shared-gpu: the ranks share one GPU, no link was crossed and the kernels of the ranks ran one after another")
+    if rank != 0:
+        return None
+    out["degraded"] = bool(degraded)
+    out["degraded_why"] = degraded
+    return out
+
+
 # --------------------------------------------------------------------------- one rank
 
 def emit_line(out):
@@ -253,6 +382,8 @@ def parse_args():
                     help="N = 1, fused path: after the timed region, keep running the same step for this many seconds and report the "
                          "rate over it (`sustained`): the K timed steps are 20-50 ms of load, this is what the device holds for "
                          "seconds (clocks, temperature).  0 skips it; so does --no-cpu-baseline (a quick run).")
+    ap.add_argument("--no-stripe-leg", action="store_true",
+                    help="N > 1, frames workload: skip the row-striped 7680x4320 plane (configs[3], ms per image) that rides on the line as `stripe`")
     ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -282,6 +413,9 @@ def parse_args():
 def worker(args):
     if int(os.environ.get("RANK", "0")) == args.fault_rank:    # test hook of the launcher's watchdog: dies before the rendezvous
         sys.exit(7)
+    # the host driver of this pool supports dmabuf IPC only: RCCL and HIP-IPC mappings between the ranks need this before the
+    # first GPU call of the process -- also under torch.distributed.run, where bench.py's own launcher has not set it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import srcnn_cpp_amd as S
@@ -302,6 +436,18 @@ def worker(args):
     dist = None
     rccl = None            # process group for device-to-device halo rows; None: stage through host memory
     rccl_world = None
+    def make_rccl():
+        """An RCCL group over the ranks, proven by an all-reduce RCCL itself sums: (group, world it summed over); raises."""
+        import datetime
+        g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+        one = torch.ones(1, device="cuda")
+        dist.all_reduce(one, group=g)
+        torch.cuda.synchronize()
+        n = int(one.item())                                    # what RCCL itself summed over: must be `world`
+        if n != world:
+            raise RuntimeError(f"RCCL reduced over {n} ranks, expected {world}")
+        return g, n
+
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -312,15 +458,8 @@ def worker(args):
         peer_form = args.workload == "stripe" and args.stripe_form == "peer" and not args.no_overlap
         # (frames exchange nothing and the peer form maps the neighbours' stripes once: no RCCL communicator is built for them)
         if args.backend == "nccl" and args.workload == "stripe" and not peer_form:
-            import datetime
             try:
-                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-                one = torch.ones(1, device="cuda")
-                dist.all_reduce(one, group=rccl)
-                torch.cuda.synchronize()
-                rccl_world = int(one.item())                   # what RCCL itself summed over: must be `world`
-                if rccl_world != world:
-                    raise RuntimeError(f"RCCL reduced over {rccl_world} ranks, expected {world}")
+                rccl, rccl_world = make_rccl()
             except Exception as e:
                 # A scaling number measured with the halo rows staged through host memory is NOT the configs[3] number:
                 # fail loudly (the launcher's watchdog stops the other ranks) unless the caller asked for the fallback,
@@ -421,15 +560,18 @@ def worker(args):
             ctx.forward_y_unfused_dev(d_in.data_ptr(), W, H * W, d_out.data_ptr(), W, H * W, W, H, F,
                                       d_work.data_ptr())
 
+    default_step = step
+
     def barrier():
         if dist is not None:
             dist.barrier()
 
     host_us = [0.0]
 
-    def timed(k_steps):
+    def timed(k_steps, step=None):
         """K steps between two HIP events on the kernels' stream; returns (this rank's start, end on the node's
         monotonic clock, kernel ms per step).  The end is taken BEFORE the closing barrier."""
+        step = step or default_step
         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         barrier()
@@ -530,6 +672,13 @@ def worker(args):
             dist.all_gather(parts, t)
             crcs = [int(v) for p in parts for v in p]
 
+    # The OTHER half of the metric ("MPix/s AND ms/image at 1/2/4/8"): ms per image at N > 1 is ONE plane row-striped over the
+    # ranks (BASELINE configs[3]).  The driver's one command per N is the frames workload above; this leg rides on it, after
+    # its timed region, so that the same line carries both curves.  Never `value`.
+    stripe_obj = None
+    if (world > 1 and not stripe and args.path == "fused" and args.mode == "mfma" and F == 1 and not args.no_stripe_leg):
+        stripe_obj = stripe_leg(args, S, torch, dist, ctx, world, rank, timed, make_rccl)
+
     if rank == 0:
         pix_per_step = W * H if stripe else W * H * F * world
         value = pix_per_step * args.steps / elapsed / 1e6
@@ -600,6 +749,8 @@ def worker(args):
                                    "H2D + kernel + D2H of neighbouring frames overlapped on two lanes" if F > 1 else ": row bands")}
         if pmc_ref:
             out["pmc_reference"] = pmc_ref
+        if stripe_obj is not None:
+            out["stripe"] = stripe_obj
         if world > 1:
             out["degraded"] = bool(degraded)
             out["distributed"] = {"control_plane": "gloo", "rccl_world": rccl_world,
