@@ -34,7 +34,10 @@ UNITS = [
     # ... and the same strip kernels with every MFMA <-> vector-ALU hazard visible to the compiler (namespace srcnn::safe,
     # launch_strip_safe): what a context launches when the interlock probe fails on its device
     ("srcnn_mfma.hip", ["-fno-slp-vectorize", "-DSRCNN_SAFE_HAZARDS=1"], "srcnn_mfma_safe"),
-    ("srcnn_probe.hip", []),
+    # the probe must run the FAST row body's sequences as the strip kernels have them: accumulators in architectural VGPRs
+    # (left alone the compiler moves the second chain to AGPRs and pads the read-back: another dependency than the one probed;
+    # tests/test_abi.py checks the listing)
+    ("srcnn_probe.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
     # MFMA results are consumed by vector instructions: keep them in architectural VGPRs (the 1-wave/SIMD
     # variant pins its weight fragments to AGPRs instead)
     ("srcnn_split16.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),

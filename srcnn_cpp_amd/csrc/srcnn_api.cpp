@@ -83,7 +83,7 @@ int srcnn_create(srcnn_ctx **out, int device)
     {
         std::lock_guard<std::mutex> lk(probe_mutex);
         if ((int)probe_result.size() < n) probe_result.resize((size_t)n, -2);
-        if (probe_result[(size_t)device] == -2) probe_result[(size_t)device] = interlock_probe_mismatches(device);
+        if (probe_result[(size_t)device] == -2) probe_result[(size_t)device] = interlock_probe_mismatches(device, c->own_stream);
         bad = probe_result[(size_t)device];
     }
     const char *force = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FORCE_SAFE");      // test knob: behave as if the probe had failed

@@ -201,7 +201,7 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
 hipError_t launch_strip_safe(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 // Does this device interlock the inline-asm MFMA -> packed multiply -> MFMA sequences of the fast row body?  Runs them with and
 // without wait states (srcnn_probe.hip); returns the number of results that differ (0 = interlocked), negative on a HIP error.
-long interlock_probe_mismatches(int device);
+long interlock_probe_mismatches(int device, hipStream_t stream);
 
 size_t split16_lds_bytes();
 hipError_t launch_split16(const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void interlock_probe_kernel(const float *__res
     out[t] = r;
 }
 
-long interlock_probe_mismatches(int device)
+// `st`: a stream of the caller's on `device` (srcnn_create passes the context's own non-blocking stream: launching on the legacy
+// null stream would synchronise with every blocking stream of the host application).
+long interlock_probe_mismatches(int device, hipStream_t st)
 {
     // 512 workgroups of 256 threads: two on every CU at once, the strip kernels' occupancy
     constexpr int kThreads = 256, kBlocks = 512, n = kThreads * kBlocks;
@@ -82,14 +84,15 @@ long interlock_probe_mismatches(int device)
     long bad = -1;
     if (hipMalloc(&d_in, h.size() * 4) == hipSuccess && hipMalloc(&d_a, (size_t)n * 4) == hipSuccess &&
         hipMalloc(&d_b, (size_t)n * 4) == hipSuccess &&
-        hipMemcpy(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        hipMemcpyAsync(d_in, h.data(), h.size() * 4, hipMemcpyHostToDevice, st) == hipSuccess) {
         bad = 0;
         std::vector<float> ra((size_t)n), rb((size_t)n);
         for (int rep = 0; rep < 2 && bad >= 0; ++rep) {
-            hipLaunchKernelGGL(interlock_probe_kernel<false>, dim3(kBlocks), dim3(kThreads), 0, 0, d_in, d_a, 24);
-            hipLaunchKernelGGL(interlock_probe_kernel<true>, dim3(kBlocks), dim3(kThreads), 0, 0, d_in, d_b, 24);
-            if (hipGetLastError() != hipSuccess || hipMemcpy(ra.data(), d_a, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(rb.data(), d_b, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            hipLaunchKernelGGL(interlock_probe_kernel<false>, dim3(kBlocks), dim3(kThreads), 0, st, d_in, d_a, 24);
+            hipLaunchKernelGGL(interlock_probe_kernel<true>, dim3(kBlocks), dim3(kThreads), 0, st, d_in, d_b, 24);
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(ra.data(), d_a, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(rb.data(), d_b, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) {
                 bad = -1;
                 break;
             }
@@ -101,6 +104,7 @@ long interlock_probe_mismatches(int device)
             if (nonzero < n / 2) bad += n;          // a probe that computes nothing proves nothing
         }
     }
+    (void)hipStreamSynchronize(st);
     if (d_in) (void)hipFree(d_in);
     if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);

@@ -184,6 +184,42 @@ def test_exact_kernels_have_no_fused_multiply_add(tmp_path, unit):
         assert banned not in asm, banned
 
 
+def test_interlock_probe_runs_the_strip_kernels_own_sequences(tmp_path):
+    """srcnn_create's interlock probe (csrc/srcnn_probe.hip) is only evidence if its no-wait kernel issues the FAST row body's
+    dependent pairs back to back (advisor, round 4): the MFMA, then the eight packed clamp multiplies rewriting ITS registers in
+    place, then an MFMA reading the first rewritten register -- no copy through AGPRs, no v_mov and no more than the one-cycle
+    s_nop the assembler's own rules ask for in between.  Checked on the listing the build's flags produce."""
+    import re
+    import subprocess
+    flags = [u[1] for u in B.UNITS if u[0] == "srcnn_probe.hip"][0]
+    out = tmp_path / "probe.s"
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, f"-I{B.CSRC}", "-S", "--cuda-device-only",
+                    "-o", str(out), str(B.CSRC / "srcnn_probe.hip")], check=True, stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    m = re.search(r"^(\S*interlock_probe_kernelILb0\S*):", text, re.M)
+    body = text[m.end():text.index(".Lfunc_end", m.end())]
+    ins = [l.split(";")[0].strip() for l in body.splitlines()]
+    # (scalar-ALU bookkeeping of the probe's loop -- its counter -- issues beside the vector stream and is no wait state of note)
+    ins = [i for i in ins if i and not i.startswith(".") and not i.endswith(":") and not re.match(r"s_(add|cmp|mov|sub)", i)]
+    assert not any(i.startswith("v_accvgpr") for i in ins), "the probe's accumulators must stay in architectural VGPRs"
+    mfma = [k for k, i in enumerate(ins) if i.startswith("v_mfma_f32_32x32x2")]
+    assert len(mfma) == 1 + 16 + 16          # one MFMA feeding the first clamp, then the two 16-step chains
+    chains = 0
+    for k in mfma:
+        dst = re.match(r"v_mfma_f32_32x32x2_f32 v\[(\d+):(\d+)\]", ins[k])
+        nxt = ins[k + 1:k + 9]
+        if dst and all(n.startswith("v_pk_mul_f32") and "clamp" in n for n in nxt):
+            lo = int(dst.group(1))
+            # (1) the eight multiplies rewrite exactly the MFMA's result registers, in place, directly behind it
+            assert [re.match(r"v_pk_mul_f32 v\[(\d+):", n).group(1) for n in nxt] == [str(lo + 2 * q) for q in range(8)], (ins[k], nxt)
+            assert all(re.match(r"v_pk_mul_f32 (v\[\d+:\d+\]), \1,", n) for n in nxt)
+            # (2)/(3) the next MFMA reads the first rewritten register as its B operand, at most an `s_nop 0` in between
+            follow = [i for i in ins[k + 9:k + 11] if i != "s_nop 0"]
+            assert follow[0].startswith("v_mfma_f32_32x32x2") and re.search(rf", v\d+, v{lo}, ", follow[0] + " "), follow
+            chains += 1
+    assert chains == 2, "both rewritten accumulators (layer 1 -> 2, layer 2 -> 3) must be probed"
+
+
 class _NoCall:
     """Stands in for the C library: the binding must reject a bad call BEFORE reaching the ABI."""
     def __getattr__(self, name):

@@ -288,3 +288,31 @@ def test_bench_under_torch_distributed_run():
     assert d["timing"]["closing_barrier_ms"] >= 0 and d["cold_start"]["ms_per_step"] > 0
     one = run_bench("--gpus", 1, "--frames", 2, "--width", 1920, "--height", 1080)
     assert d["config"]["output_crc32"] == one["config"]["output_crc32"]
+    # ... and the same line carries the row-striped configs[3] plane (RCCL refuses two ranks on one GPU: the halo form says so and
+    # stages through the host; HSA_ENABLE_IPC_MODE_LEGACY is set by the worker itself, so the IPC form maps under this launcher too)
+    st = d["stripe"]
+    assert st["degraded"] is True and st["forms"]["halo"]["sha256_equals_golden"] is True
+    assert st["forms"]["halo"]["halo_transport"].startswith("host-staged") and "rccl_error" in st["forms"]["halo"]
+    assert st["forms"]["peer"].get("sha256_equals_golden") is True, st["forms"]["peer"]
+
+
+def test_bench_frames_line_carries_the_striped_plane():
+    """ONE driver command per N must yield both halves of the metric.  `bench.py --gpus N` (frames, weak
+    scaling: `value`) now also row-stripes the 7680x4320 plane of BASELINE configs[3] over its N ranks after the timed region
+    and reports ms per image per transport in `stripe`: the stitched plane's sha256 is checked in-line against
+    tests/golden/config_checksums.json, RCCL's own rank count and the transport are stated, anything else is `degraded`."""
+    d = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--steps", 4)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["width"] == 3840
+    one = run_bench("--gpus", 1, "--frames", 2, "--steps", 4)
+    assert d["config"]["output_crc32"] == one["config"]["output_crc32"]          # the frames figure's planes are untouched
+    st = d["stripe"]
+    gold = json.loads((ROOT / "tests" / "golden" / "config_checksums.json").read_text())["c3_7680x4320"]["gpuorder_sha256"][0]
+    assert st["golden_sha256"] == gold and st["one_gpu_reference"]["ms"] > 3
+    for form in ("halo", "peer"):
+        f = st["forms"][form]
+        assert f["output_sha256"] == gold and f["sha256_equals_golden"] is True, (form, f)
+        assert f["ms_per_image"] > 0 and len(f["per_rank_ms"]) == 2 and f["speedup_vs_one_gpu"] > 0
+    assert st["forms"]["halo"]["halo_transport"] == "host-staged (gloo)" and st["forms"]["halo"]["rccl_world"] is None
+    assert st["degraded"] is True and any("shared" in w for w in st["degraded_why"])       # two ranks on one GPU is a smoke configuration
+    off = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--steps", 3, "--no-stripe-leg")
+    assert "stripe" not in off
