@@ -382,6 +382,11 @@ def parse_args():
                     help="N = 1, fused path: after the timed region, keep running the same step for this many seconds and report the "
                          "rate over it (`sustained`): the K timed steps are 20-50 ms of load, this is what the device holds for "
                          "seconds (clocks, temperature).  0 skips it; so does --no-cpu-baseline (a quick run).")
+    ap.add_argument("--seam-deferral", choices=["on", "off"], default="on",
+                    help="fused float32 path, one plane per step: on (default) = srcnn_set_seam_deferral(1), the K steps are queued back to "
+                         "back and the seam blocks of step k ride behind the work items of step k + 1 instead of a launch of their own; "
+                         "the last step's are queued (srcnn_flush) INSIDE the timed region, before its closing event.  off = one seam "
+                         "launch per step (rounds 1-4).  Same bytes.")
     ap.add_argument("--no-stripe-leg", action="store_true",
                     help="N > 1, frames workload: skip the row-striped 7680x4320 plane (configs[3], ms per image) that rides on the line as `stripe`")
     ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
@@ -483,6 +488,9 @@ def worker(args):
         ctx.set_mode(S.MODE_REFBYTES)
     elif args.mode == "refbytes16":                                # opt-in: split-f16 kernel + exact fix-up
         ctx.set_mode(S.MODE_REFBYTES16)
+    deferral = args.seam_deferral == "on" and args.mode == "mfma" and args.path == "fused"
+    if deferral:
+        ctx.set_seam_deferral(True)
     if args.fix_margin is not None:
         ctx.set_fixup_margin(args.fix_margin)
     if args.no_fix_strict:
@@ -587,6 +595,8 @@ def worker(args):
         ev_a.record(stream)
         for _ in range(k_steps):
             step()
+        if deferral:
+            ctx.flush()                # the last step's deferred seam launch: queued inside the timed region
         host_us[0] = (time.perf_counter() - t_a) / max(1, k_steps) * 1e6     # everything queued: the host's share of a step
         ev_b.record(stream)
         torch.cuda.synchronize()
@@ -721,6 +731,7 @@ def worker(args):
                                    "arithmetic, " + ("host buffers over PCIe" if args.path in ("host", "surface", "surface-dev")
                                                      else "inputs resident in HBM"),
                        "frames_per_gpu": F, "width": W, "height": H, "path": args.path, "mode": args.mode,
+                       "seam_deferral": bool(deferral),
                        "plan": ctx.query_plan(W, r1 - r0 if stripe else H, F), "output_checksum": chk,
                        "output_crc32": crcs},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
@@ -790,6 +801,8 @@ def worker(args):
                 ea.record(stream)
                 for _ in range(chunk):
                     step()
+                if deferral:
+                    ctx.flush()
                 eb.record(stream)
                 eb.synchronize()
                 per_chunk.append(ea.elapsed_time(eb) / chunk)

@@ -107,6 +107,17 @@ int srcnn_set_stream(srcnn_ctx *ctx, void *hip_stream);
 /* Block until all work queued by this context has finished. */
 int srcnn_synchronize(srcnn_ctx *ctx);
 
+/* SEAM DEFERRAL, for callers that queue fused launches back to back on one stream (the frames of a stream, the steps of a
+ * row-striped plane).  A fused float32 launch is followed by a small second launch that finishes the pixels on the seams between
+ * its work items (~8 us + a launch boundary: 1 % of a 3840x2160 step, 3 % of a 1920x1080 one).  With deferral ON that second
+ * launch of srcnn_forward_y_dev / srcnn_forward_y_rows_dev / srcnn_forward_y_rows_halo_dev is NOT queued: its blocks ride behind
+ * the work items of the context's NEXT such launch on the same stream, in the tail where compute units would otherwise idle.
+ * CONTRACT: the last launch's output is complete on the stream only after srcnn_flush(ctx) (queues the pending seam work, does not
+ * wait) or after ANY other call on the context (srcnn_synchronize included) -- a caller that enqueues its own work reading the
+ * output calls srcnn_flush first.  Same bytes either way.  Off by default; SRCNN_MODE_MFMA only (the other modes ignore it). */
+int srcnn_set_seam_deferral(srcnn_ctx *ctx, int on);
+int srcnn_flush(srcnn_ctx *ctx);
+
 /* Which instantiation of the MFMA strip kernels this context launches: 0 = the fast one, whose row body relies on the
  * hardware interlocking three MFMA <-> vector-ALU operand dependencies -- verified on this device by running exactly those
  * instruction sequences with and without wait states at srcnn_create (once per device and process, ~1 ms); 1 = the

@@ -135,6 +135,8 @@ def load_library() -> C.CDLL:
         "srcnn_query_plan": ([vp, i, i, i, C.POINTER(i * 6)], i),
         "srcnn_fixup_stats": ([vp, C.POINTER(C.c_ulonglong * 4), C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
         "srcnn_set_fixup_strict": ([vp, i], i),
+        "srcnn_set_seam_deferral": ([vp, i], i),
+        "srcnn_flush": ([vp], i),
         "srcnn_set_fixup_margin": ([vp, C.c_float], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
@@ -162,7 +164,7 @@ ABI_SYMBOLS = (
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
-    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_set_seam_deferral", "srcnn_flush", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
 )
@@ -335,6 +337,16 @@ class Context:
         """SRCNN_MODE_REFBYTES: redo a launch in the reference's arithmetic on every pixel when its monitored deviation exceeds
         delta / 2 -- on the device, no host read; ON by default."""
         self._check(self._lib.srcnn_set_fixup_strict(self._h, int(bool(on))))
+
+    def set_seam_deferral(self, on: bool = True):
+        """Fused float32 launches queued back to back: the seam blocks of a launch ride behind the NEXT launch's work items instead
+        of a launch of their own (srcnn_set_seam_deferral).  The last launch's output is complete only after ``flush()`` or any
+        other call on the context."""
+        self._check(self._lib.srcnn_set_seam_deferral(self._h, int(bool(on))))
+
+    def flush(self):
+        """Queue pending deferred seam work on its stream (srcnn_flush; does not wait)."""
+        self._check(self._lib.srcnn_flush(self._h))
 
     def set_fixup_margin(self, factor: float):
         """SRCNN_MODE_REFBYTES: delta = factor x (noise scale of the model) + absolute term; default 4."""

@@ -104,6 +104,7 @@ void srcnn_destroy(srcnn_ctx *c)
     if (!c) return;
     c->pool.reset();                       // parks no more workers: joins them
     DeviceScope dev_scope_(c);
+    (void)flush_seams(c);
     (void)hipStreamSynchronize(c->stream);
     (void)hipDeviceSynchronize();          // work on any stream the context was given may still use its buffers
     for (DevBuf *b : {&c->wfrag, &c->wraw, &c->in_u8, &c->out_u8, &c->pre_f32, &c->planes, &c->plane1, &c->kern, &c->sink,
@@ -123,6 +124,8 @@ void srcnn_destroy(srcnn_ctx *c)
     for (auto &sc : c->seam_scratch) {
         release(sc.buf);
         release(sc.cbuf);
+        release(sc.buf2);
+        release(sc.cbuf2);
         release(sc.flag);
         release(sc.fix_lists);
         release(sc.fix_counters);
@@ -151,6 +154,7 @@ int srcnn_set_mode(srcnn_ctx *c, int mode)
     if (!c || (mode != SRCNN_MODE_MFMA && mode != SRCNN_MODE_EXACT && mode != SRCNN_MODE_SPLIT16 && mode != SRCNN_MODE_REFBYTES &&
                mode != SRCNN_MODE_REFBYTES16))
         return SRCNN_ERR_INVALID;
+    BIND(c);
     c->mode = mode;
     return SRCNN_OK;
 }
@@ -159,8 +163,21 @@ int srcnn_get_mode(const srcnn_ctx *c) { return c ? c->mode : SRCNN_ERR_INVALID;
 
 int srcnn_set_stream(srcnn_ctx *c, void *hip_stream)
 {
-    if (!c) return SRCNN_ERR_INVALID;
+    BIND(c);                               // (deferred seam work belongs to the stream it was deferred on: queued there first)
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return SRCNN_OK;
+}
+
+int srcnn_set_seam_deferral(srcnn_ctx *c, int on)
+{
+    BIND(c);
+    c->defer_seams = on != 0;
+    return SRCNN_OK;
+}
+
+int srcnn_flush(srcnn_ctx *c)
+{
+    BIND(c);
     return SRCNN_OK;
 }
 

@@ -156,6 +156,8 @@ struct srcnn_ctx {
         hipStream_t stream = nullptr;
         bool used = false;
         srcnn::host::DevBuf buf, cbuf;           // row seams, column seams
+        srcnn::host::DevBuf buf2, cbuf2;         // ... the second set of seam deferral (launches alternate: `flip`)
+        int flip = 0;
         srcnn::host::DevBuf flag, fix_lists, fix_counters;     // SRCNN_MODE_REFBYTES: flag plane, work lists, per-launch counters
     };
     SeamScratch seam_scratch[4];
@@ -205,6 +207,15 @@ struct srcnn_ctx {
     srcnn::host::DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
     size_t pin_cap = 0;
+    // Seam deferral (srcnn_set_seam_deferral): the seam launch of the last fused single-plane launch has NOT been queued yet; the
+    // next such launch on the same stream carries its blocks (srcnn_strip_fold_kernel), anything else on the context queues it
+    // first (flush_seams(): every entry point through BIND, the item-table eviction, srcnn_flush, srcnn_destroy).
+    bool defer_seams = false;
+    struct PendingSeams {
+        bool valid = false;
+        hipStream_t stream = nullptr;
+        srcnn::FoldParams f{};
+    } pending;
     float fix_delta = 0.f;                 // SRCNN_MODE_REFBYTES: flag threshold for the uploaded model (fixup_delta())
     float fix_margin = kFixMargin;         // ... the factor of its weight-proportional term (srcnn_set_fixup_margin)
     bool fix_strict = true;                // ... act on the monitor: a launch whose max_dev > delta / 2 is redone in the reference's arithmetic (fix_rerun_kernel)
@@ -247,9 +258,13 @@ struct DeviceScope {
     DeviceScope(const DeviceScope &) = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
-#define BIND(c)                 \
+// BIND_KEEP: the entry points whose launch can CARRY deferred seam work (run_strip decides); BIND: everything else queues it first.
+#define BIND_KEEP(c)            \
     DeviceScope dev_scope_(c);  \
     if (dev_scope_.rc) return dev_scope_.rc
+#define BIND(c)                                                        \
+    BIND_KEEP(c);                                                      \
+    if (int flush_rc_ = srcnn::host::flush_seams(c)) return flush_rc_
 
 int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes);
 void release(DevBuf &b);
@@ -305,7 +320,9 @@ bool ranges_overlap(const void *a, size_t a_bytes, const void *b, size_t b_bytes
 size_t span_elems(size_t stride, size_t frame_pitch, int width, int height, int n_frames);
 bool bad_plane(const void *p, size_t stride, int w, int h);
 bool bad_pitch(size_t plane_pitch);
-int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame = 0, int fix_frames = 1);
+// may_defer: the caller is one of the device entry points whose contract allows seam deferral (srcnn_set_seam_deferral)
+int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame = 0, int fix_frames = 1, bool may_defer = false);
+int flush_seams(srcnn_ctx *c);
 
 // ---- srcnn_host.cpp ----
 void cubic_table(int n_src, int n_dst, int *ofs, short *coef);

@@ -197,6 +197,15 @@ hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)
 hipError_t launch_seams_merged(const StripParams &p, int n_seams, const int *d_seams, const unsigned char *d_winmap, int n_frames,
                                hipStream_t stream);
 hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
+// A fused float32 single-plane launch that also carries the seam blocks of the launch BEFORE it (seam deferral, srcnn_mfma.hip):
+// blocks [0, first_block) are p's work items, the n_seams + cblocks behind them finish `prev`'s row and column seams.
+struct FoldParams {
+    StripParams prev;
+    const int *seams;               // prev's seam table {strip, row} per seam
+    const unsigned char *winmap;    // prev's rows inside a seam window, per strip
+    int n_seams, cblocks, first_block;
+};
+hipError_t launch_strip_fold(const StripParams &p, const FoldParams &f, hipStream_t stream, size_t lds_pad = 0);
 // the same kernels with every MFMA <-> vector-ALU hazard visible to the compiler (srcnn_mfma.hip built with -DSRCNN_SAFE_HAZARDS=1)
 hipError_t launch_strip_safe(int mode, const StripParams &p, int n_frames, hipStream_t stream, size_t lds_pad = 0);
 // Does this device interlock the inline-asm MFMA -> packed multiply -> MFMA sequences of the fast row body?  Runs them with and

@@ -28,10 +28,20 @@ bool bad_plane(const void *p, size_t stride, int w, int h)
 // the kernels address a lane's plane element with a 32-bit offset from a per-plane scalar base
 bool bad_pitch(size_t plane_pitch) { return plane_pitch >= ((size_t)1 << 29); }
 
+// Seam deferral: queue the seam launch a fused launch left pending (srcnn_ctx::PendingSeams), on the stream it belongs to.
+int flush_seams(srcnn_ctx *c)
+{
+    if (!c || !c->pending.valid) return SRCNN_OK;
+    c->pending.valid = false;
+    const FoldParams &f = c->pending.f;
+    HIP_TRY(c, launch_seams_merged(f.prev, f.n_seams, f.seams, f.winmap, 1, c->pending.stream));
+    return SRCNN_OK;
+}
+
 // Common launch of the three strip modes on device memory.
 // fix_frame / fix_frames (SRCNN_MODE_REFBYTES only): this single-frame launch is frame `fix_frame` of a batch of `fix_frames`
 // whose flagged pixels ONE fix-up finishes, queued behind the batch's last launch (fix_frames = 1: the launch's own fix-up).
-int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame, int fix_frames)
+int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame, int fix_frames, bool may_defer)
 {
     const int halo = (mode == MODE_L12) ? 0 : 2;
     // Undocumented experiment knobs (never set in production).  Only bits that leave every output byte as it is are honoured:
@@ -59,6 +69,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
     p.cseam = nullptr;
     p.strips_total = pl.n_strips;
     int grid_items = 0;
+    bool defer = false;                  // seam deferral: leave this launch's seam work pending (see below)
     const srcnn_ctx::ItemTable *table = nullptr;
     // Convolution55 alone (MODE_L3) reads 128 B per pixel and is bound by HBM: strips of exactly FW = 128 columns
     // (column seams instead of 2 halo columns each side), so that the four waves of a workgroup read four whole
@@ -133,14 +144,21 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
                 }
                 sc->used = true;
                 sc->stream = c->stream;
+                // Seam deferral: this launch's seam blocks will ride behind the NEXT launch's work items, which writes its own
+                // exports meanwhile -- the two scratch sets of the stream are used in turn.
+                defer = may_defer && c->defer_seams && !c->safe_hazards && fused32 && n_frames == 1 && !p.pre && !(p.tune & 16) &&
+                        table->separated && table->n_seams > 0 && col_seams &&
+                        !(c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16);
+                if (defer) sc->flip ^= 1;
+                DevBuf &rbuf = defer && sc->flip ? sc->buf2 : sc->buf, &cbuf = defer && sc->flip ? sc->cbuf2 : sc->cbuf;
                 if (table->n_seams > 0) {
-                    if ((rc = reserve(c, sc->buf, (size_t)n_frames * table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
-                    p.seam = static_cast<float *>(sc->buf.p);
+                    if ((rc = reserve(c, rbuf, (size_t)n_frames * table->n_seams * SEAM_FLOATS * NTHREADS * sizeof(float)))) return rc;
+                    p.seam = static_cast<float *>(rbuf.p);
                 }
                 if (col_seams) {
                     const size_t n = (size_t)n_frames * p.strips_total * (p.row_end - p.row_begin) * CSEAM_FLOATS * sizeof(float);
-                    if ((rc = reserve(c, sc->cbuf, n))) return rc;
-                    p.cseam = static_cast<float *>(sc->cbuf.p);
+                    if ((rc = reserve(c, cbuf, n))) return rc;
+                    p.cseam = static_cast<float *>(cbuf.p);
                 }
             }
             p.n_strips = 1;            // grid = n_strips * n_segs * n_frames blocks
@@ -221,14 +239,35 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         if (!c->split16_ok)
             return fail(c, SRCNN_ERR_STATE, "SRCNN_MODE_SPLIT16: these weights exceed the f16 ranges of the mode "
                                             "(layer maps must stay below 8192 / 16384 for 8-bit input); use SRCNN_MODE_MFMA");
+        int rc;
+        if ((rc = flush_seams(c))) return rc;
         HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
     }
-    else HIP_TRY(c, (c->safe_hazards ? launch_strip_safe : launch_strip)(mode, p, n_frames, c->stream, pad));
+    else if (c->pending.valid && defer && c->pending.stream == c->stream && grid_items > 0) {
+        // the previous launch's seam blocks ride behind this launch's work items (srcnn_strip_fold_kernel)
+        c->pending.f.first_block = grid_items;
+        c->pending.valid = false;
+        HIP_TRY(c, launch_strip_fold(p, c->pending.f, c->stream, pad));
+    } else {
+        int rc;
+        if ((rc = flush_seams(c))) return rc;
+        HIP_TRY(c, (c->safe_hazards ? launch_strip_safe : launch_strip)(mode, p, n_frames, c->stream, pad));
+    }
     // Row seams and column seams in ONE launch when the plan keeps the seam windows of neighbouring strips apart
     // (plan_items_balanced()): the blocks that finish a row seam then also finish the column-seam pixels of their four
     // rows, the column-seam blocks skip those rows, and neither waits for the other.
     static const char *env_merge = SRCNN_DEBUG_ENV("SRCNN_DEBUG_SEAM_MERGE");      // experiment knob: 0 = two launches
-    if (p.seam && p.cseam && table->separated && !(env_merge && std::atoi(env_merge) == 0)) {
+    if (defer && !(env_merge && std::atoi(env_merge) == 0)) {
+        FoldParams &f = c->pending.f;
+        f.prev = p;
+        f.seams = static_cast<const int *>(table->dev_seams.p);
+        f.winmap = static_cast<const unsigned char *>(table->dev_winmap.p);
+        f.n_seams = table->n_seams;
+        f.cblocks = (int)(((long)(p.strips_total - 1) * (p.row_end - p.row_begin) + 255) / 256);
+        f.first_block = 0;
+        c->pending.stream = c->stream;
+        c->pending.valid = true;
+    } else if (p.seam && p.cseam && table->separated && !(env_merge && std::atoi(env_merge) == 0)) {
         HIP_TRY(c, launch_seams_merged(p, table->n_seams * n_frames, static_cast<const int *>(table->dev_seams.p),
                                        static_cast<const unsigned char *>(table->dev_winmap.p), n_frames, c->stream));
     } else {
@@ -395,7 +434,7 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
                         uint8_t *d_dst, size_t dst_stride, size_t dst_frame_pitch, int width, int height,
                         int n_frames, float *d_preclamp)
 {
-    BIND(c);
+    BIND_KEEP(c);
     int rc = SRCNN_OK;
     (void)rc;
     if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
@@ -408,6 +447,7 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
         return fail(c, SRCNN_ERR_INVALID, "forward_y_dev: src and dst overlap (the path cannot run in place)");
     // (a pre-clamp request in REFBYTES mode wants the REFERENCE's float too: the exact kernels deliver both)
     if (c->mode == SRCNN_MODE_EXACT || ((c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16) && d_preclamp)) {
+        if ((rc = flush_seams(c))) return rc;
         // frame by frame through ONE 32-plane workspace (128 B/pixel), whatever the batch size
         const long pitch = (long)width * height;
         if ((rc = reserve(c, c->planes, (size_t)32 * pitch * 4))) return rc;
@@ -425,6 +465,15 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
     }
     // the seam scratch of a launch grows with its frames: frames_per_launch() bounds it
     const int kMaxFrames = frames_per_launch(c, width, height, n_frames);
+    // A batch that runs as one single-plane launch per frame defers its own seam launches: frame k's seam blocks ride behind
+    // frame k + 1's work items, the last frame's are queued before the call returns (unless the caller asked for deferral).
+    const bool caller_defers = c->defer_seams;
+    if (n_frames > 1 && kMaxFrames == 1) c->defer_seams = true;
+    struct Restore {
+        srcnn_ctx *c;
+        bool v;
+        ~Restore() { c->defer_seams = v; }
+    } restore{c, caller_defers};
     for (int f0 = 0; f0 < n_frames; f0 += kMaxFrames) {
         StripParams p{};
         p.src = d_src + (size_t)f0 * src_frame_pitch;
@@ -444,9 +493,10 @@ int srcnn_forward_y_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, s
             1ull, std::min<unsigned long long>(FIX_BATCH_FRAMES, 0xffffffffull / ((unsigned long long)width * height)));
         const int batch0 = f0 - f0 % fix_batch;
         if ((rc = run_strip(c, MODE_FUSED, p, std::min(kMaxFrames, n_frames - f0), refbytes ? f0 - batch0 : 0,
-                            refbytes ? std::min(fix_batch, n_frames - batch0) : 1)))
+                            refbytes ? std::min(fix_batch, n_frames - batch0) : 1, /*may_defer=*/true)))
             return rc;
     }
+    if (!caller_defers && (rc = flush_seams(c))) return rc;
     return SRCNN_OK;
 }
 
@@ -454,7 +504,7 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
                              uint8_t *d_dst, size_t dst_stride, int dst_row0, int width, int height,
                              int row_begin, int row_end)
 {
-    BIND(c);
+    BIND_KEEP(c);
     int rc = SRCNN_OK;
     (void)rc;
     if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
@@ -474,7 +524,7 @@ int srcnn_forward_y_rows_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stri
     p.height = height;
     p.row_begin = row_begin;
     p.row_end = row_end;
-    return run_strip(c, MODE_FUSED, p, 1);
+    return run_strip(c, MODE_FUSED, p, 1, 0, 1, /*may_defer=*/true);
 }
 
 int srcnn_forward_y_rows_halo_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src_stride, int src_row0, int src_rows,
@@ -482,7 +532,7 @@ int srcnn_forward_y_rows_halo_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src
                                   uint8_t *d_dst, size_t dst_stride, int dst_row0, int width, int height,
                                   int row_begin, int row_end)
 {
-    BIND(c);
+    BIND_KEEP(c);
     if (!has_model(c)) return fail(c, SRCNN_ERR_STATE, "%s", kNoModel);
     const int src_row1 = src_row0 + src_rows;
     if (bad_plane(d_src, src_stride, width, height) || bad_plane(d_dst, dst_stride, width, height) || src_rows <= 0 ||
@@ -514,7 +564,7 @@ int srcnn_forward_y_rows_halo_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src
     p.height = height;
     p.row_begin = row_begin;
     p.row_end = row_end;
-    return run_strip(c, MODE_FUSED, p, 1);
+    return run_strip(c, MODE_FUSED, p, 1, 0, 1, /*may_defer=*/true);
 }
 
 

@@ -241,8 +241,10 @@ constexpr bool fast_kernel(int mode, bool pre, int diag)
 // HALO3: a row stripe whose 6 halo rows either side lie in buffers of their own (StripParams::src_top / src_bot): the Y row
 // address is a scalar select per row, nothing else changes -- one launch per stripe of a row-striped plane, no band launches
 // and no copy of the stripe next to its halo rows.
+// (The body is a function of its own so that two kernels can run it: srcnn_strip_kernel, and srcnn_strip_fold_kernel below, whose
+// grid carries the seam blocks of the PREVIOUS launch behind its own work items.)
 template <int MODE, bool PRE, int DIAG = 0, bool FIX = false, bool HALO3 = false>
-__global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
+__device__ __forceinline__ void strip_body(const StripParams &p)
 {
     static_assert(!FIX || (MODE == MODE_FUSED && !PRE && DIAG == 0), "flags belong to the production fused kernel");
     static_assert(!HALO3 || (MODE == MODE_FUSED && !PRE && DIAG == 0), "halo buffers belong to the production fused kernel");
@@ -819,6 +821,12 @@ __global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip
     }
 }
 
+template <int MODE, bool PRE, int DIAG = 0, bool FIX = false, bool HALO3 = false>
+__global__ __launch_bounds__(NTHREADS, MODE == MODE_L3 ? 4 : 2) void srcnn_strip_kernel(const StripParams p)
+{
+    strip_body<MODE, PRE, DIAG, FIX, HALO3>(p);
+}
+
 }  // namespace SRCNN_KNS
 using namespace SRCNN_KNS;
 
@@ -982,6 +990,36 @@ __global__ __launch_bounds__(NTHREADS) void srcnn_seams_merged_kernel(const Stri
         const int q = (int)blockIdx.x - n_seams;
         cseam_block<PRE, FIX>(p, (long)(q % cblocks_per_frame), q / cblocks_per_frame, winmap);
     }
+}
+
+size_t strip_lds_bytes(int mode);
+
+// SEAM DEFERRAL (srcnn_set_seam_deferral).  A stream of launches queued back to back pays one seam launch per step: ~8 us of
+// kernel and a launch boundary, 1 % of a 3840x2160 step, 3 % of a 1920x1080 one, 2 % of a 540-row stripe of a 7680x4320 plane.
+// In this kernel the seam blocks of launch k ride BEHIND the work items of launch k + 1: they are dispatched as the first strip
+// blocks finish and run on the CUs that would otherwise idle until the slowest one is done (13 us on average).  No block waits
+// for another one: the seam scratch they read was completed by launch k, a finished kernel, and launch k + 1 writes the other of
+// two scratch sets.  Float32 MFMA mode, single planes with explicit work items and a separated seam plan only (run_strip()).
+template <bool HALO3>
+__global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_fold_kernel(const StripParams p, const FoldParams f)
+{
+    if ((int)blockIdx.x >= f.first_block) {         // (uniform per block)
+        const int q = (int)blockIdx.x - f.first_block;
+        if (q < f.n_seams) seam_block<false, true, false>(f.prev, f.seams, q);
+        else cseam_block<false, false>(f.prev, (long)(q - f.n_seams), 0, f.winmap);
+        return;
+    }
+    fast::strip_body<MODE_FUSED, false, 0, false, HALO3>(p);
+}
+
+hipError_t launch_strip_fold(const StripParams &p, const FoldParams &f, hipStream_t stream, size_t lds_pad)
+{
+    if (p.pre || p.flag || f.prev.pre || f.prev.flag || !p.items) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(f.first_block + f.n_seams + f.cblocks)), block(NTHREADS);
+    const size_t lds = strip_lds_bytes(MODE_FUSED) + lds_pad;
+    if (p.src_top || p.src_bot) hipLaunchKernelGGL((srcnn_strip_fold_kernel<true>), grid, block, lds, stream, p, f);
+    else hipLaunchKernelGGL((srcnn_strip_fold_kernel<false>), grid, block, lds, stream, p, f);
+    return hipGetLastError();
 }
 
 hipError_t launch_cseams(const StripParams &p, int n_frames, hipStream_t stream)

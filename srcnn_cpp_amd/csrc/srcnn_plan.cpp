@@ -441,7 +441,10 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
         if (t.stamp < victim->stamp) victim = &t;
     }
     const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
-    if (victim->stamp) HIP_TRY(c, hipDeviceSynchronize());              // evicting: its readers must be done
+    if (victim->stamp) {                                                // evicting: its readers must be done -- and queued
+        if (int rc = flush_seams(c)) return rc;                         // (a deferred seam launch may refer to the victim's tables)
+        HIP_TRY(c, hipDeviceSynchronize());
+    }
     if (plan.count() > 0) {
         int rc;
         if ((rc = reserve(c, victim->dev, plan.items.size() * sizeof(int)))) return rc;

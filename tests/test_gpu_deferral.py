@@ -1,0 +1,160 @@
+"""Seam deferral (srcnn_set_seam_deferral / srcnn_flush): fused float32 launches queued back to back carry
+the seam blocks of the launch before them (srcnn_strip_fold_kernel) instead of paying a seam launch each.  Speed only: every
+test here compares bytes -- with the launch-by-launch form, with oracle/srcnn_gpuorder.c's model of the kernels, and with the
+committed checksums of the full-size planes."""
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+import srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_batch, synth_luma
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.fixture
+def ctx(weights_blob):
+    c = S.Context(0)
+    c.set_weights_blob(weights_blob)
+    yield c
+    c.close()
+
+
+def test_a_stream_of_planes_equals_launch_by_launch(ctx, weights_blob):
+    """Eight DIFFERENT 1920x1080 planes queued back to back into eight outputs, deferral on: every output equals the plain form's
+    (and frame 0 the CPU model of the kernels); the last plane is complete only after flush()."""
+    import torch
+    w, h, n = 1920, 1080, 8
+    frames = synth_batch(w, h, n, first_frame=11)
+    d_in = torch.from_numpy(frames).cuda()
+    want = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    for k in range(n):
+        ctx.forward_y_dev(d_in[k].data_ptr(), w, 0, want[k].data_ptr(), w, 0, w, h, 1)
+    ctx.synchronize()
+    want = want.cpu().numpy()
+    assert np.array_equal(want[0], oracle.gpuorder_forward_y(frames[0], weights_blob)[0])
+    got = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ctx.set_seam_deferral(True)
+    for k in range(n):
+        ctx.forward_y_dev(d_in[k].data_ptr(), w, 0, got[k].data_ptr(), w, 0, w, h, 1)
+    torch.cuda.synchronize()                   # everything QUEUED so far has run: the last plane's seam pixels have not been queued
+    part = got.cpu().numpy()
+    assert all(np.array_equal(part[k], want[k]) for k in range(n - 1))
+    assert not np.array_equal(part[n - 1], want[n - 1]), "the last launch's seam work must still be pending"
+    ctx.flush()
+    ctx.synchronize()
+    assert np.array_equal(got.cpu().numpy(), want)
+    ctx.set_seam_deferral(False)
+
+
+def test_any_other_call_completes_the_pending_plane(ctx, weights_blob):
+    """The contract's safety net: ANY other entry point queues the pending seam work first -- a mode change, a host-buffer call,
+    a change of stream, a geometry that cannot carry it (another plan), srcnn_synchronize."""
+    import torch
+    w, h = 1280, 720
+    y = synth_luma(w, h, frame=2)
+    want = oracle.gpuorder_forward_y(y, weights_blob)[0]
+    d_in = torch.from_numpy(y).cuda()
+    small = synth_luma(300, 70, frame=1)
+    d_small, d_small_out = torch.from_numpy(small).cuda(), torch.zeros((70, 300), dtype=torch.uint8, device="cuda")
+    other = torch.cuda.Stream()
+    ctx.set_seam_deferral(True)
+    actions = {
+        "synchronize": lambda: ctx.synchronize(),
+        "set_mode": lambda: (ctx.set_mode(S.MODE_EXACT), ctx.set_mode(S.MODE_MFMA)),
+        "host call": lambda: ctx.forward_y(small),
+        "another geometry": lambda: ctx.forward_y_dev(d_small.data_ptr(), 300, 0, d_small_out.data_ptr(), 300, 0, 300, 70, 1),
+        "set_stream": lambda: (ctx.set_stream(other.cuda_stream), ctx.set_stream(0)),
+        "fixup_stats": lambda: ctx.fixup_stats(),
+    }
+    for name, act in actions.items():
+        d_out = torch.zeros_like(d_in)
+        torch.cuda.synchronize()
+        ctx.forward_y_dev(d_in.data_ptr(), w, 0, d_out.data_ptr(), w, 0, w, h, 1)
+        act()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), want), name
+    assert np.array_equal(d_small_out.cpu().numpy(), oracle.gpuorder_forward_y(small, weights_blob)[0])
+
+
+def test_striped_plane_steps_with_deferral(ctx, weights_blob):
+    """The steps of a row-striped plane (one launch per rank per step, halo rows in buffers of their own): four stripes of a
+    1920x1080 plane, three steps each, deferral on -- every stripe equals its rows of the whole plane."""
+    import torch
+    w, h, n = 1920, 1080, 4
+    y = synth_luma(w, h, frame=7)
+    want = oracle.gpuorder_forward_y(y, weights_blob)[0]
+    d_y = torch.from_numpy(y).cuda()
+    ctx.set_seam_deferral(True)
+    out = torch.zeros_like(d_y)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for k in range(n):
+            r0, r1 = S.stripe_rows(h, n, k)
+            own = d_y[r0:r1]
+            top = d_y[r0 - 6:r0] if k > 0 else None
+            bot = d_y[r1:r1 + 6] if k < n - 1 else None
+            ctx.forward_y_rows_halo_dev(own.data_ptr(), w, r0, r1 - r0, top.data_ptr() if top is not None else 0,
+                                        bot.data_ptr() if bot is not None else 0, w, out.data_ptr(), w, 0, w, h, r0, r1)
+    ctx.flush()
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_batches_fold_their_own_seam_launches(ctx, weights_blob):
+    """srcnn_forward_y_dev on a batch that runs as one launch per frame folds frame k's seam blocks into frame k + 1's launch by
+    itself and returns with every frame's work queued (no deferral asked for): 5 x 2560x1440 equal the frames one by one."""
+    import torch
+    w, h, n = 2560, 1440, 5
+    frames = synth_batch(w, h, n, first_frame=3)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ctx.forward_y_dev(d_in.data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, w, h, n)
+    torch.cuda.synchronize()                   # no flush: the call itself queued everything
+    got = d_out.cpu().numpy()
+    for k in (0, n - 1):
+        assert np.array_equal(got[k], oracle.gpuorder_forward_y(frames[k], weights_blob)[0]), k
+    one = torch.zeros_like(d_in[2])
+    ctx.forward_y_dev(d_in[2].data_ptr(), w, 0, one.data_ptr(), w, 0, w, h, 1)
+    ctx.synchronize()
+    assert np.array_equal(one.cpu().numpy(), got[2])
+
+
+def test_full_size_planes_with_deferral(ctx):
+    """configs[1] and configs[3] at size: the 3840x2160 plane and the 7680x4320 plane as 8 stripes of 540 rows, 3 steps each with
+    deferral on, against the committed sha256 of the kernels' model."""
+    import torch
+    pin4k = json.loads((GOLD / "synthetic_4k_checksums.json").read_text())
+    y = synth_luma(3840, 2160)
+    d_in = torch.from_numpy(y).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ctx.set_seam_deferral(True)
+    for _ in range(3):
+        ctx.forward_y_dev(d_in.data_ptr(), 3840, 0, d_out.data_ptr(), 3840, 0, 3840, 2160, 1)
+    ctx.flush()
+    ctx.synchronize()
+    assert hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest() == pin4k["gpuorder_sha256"]
+    pin = json.loads((GOLD / "config_checksums.json").read_text())["c3_7680x4320"]
+    w, h = 7680, 4320
+    d_y = torch.from_numpy(synth_luma(w, h)).cuda()
+    out = torch.zeros_like(d_y)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        for k in range(8):
+            r0, r1 = 540 * k, 540 * (k + 1)
+            own = d_y[r0:r1]
+            ctx.forward_y_rows_halo_dev(own.data_ptr(), w, r0, 540, d_y[r0 - 6:r0].data_ptr() if k else 0,
+                                        d_y[r1:r1 + 6].data_ptr() if k < 7 else 0, w, out.data_ptr(), w, 0, w, h, r0, r1)
+    ctx.flush()
+    ctx.synchronize()
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == pin["gpuorder_sha256"][0]

@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--mode", default="mfma", choices=["mfma", "refbytes"])
     ap.add_argument("--ns", default="1,2,4,8")
+    ap.add_argument("--seam-deferral", choices=["on", "off"], default="on",
+                    help="on (default, round 5): srcnn_set_seam_deferral(1) -- the seam blocks of step k ride behind the work items of step "
+                         "k + 1, the last step's are queued (srcnn_flush) inside the timed window; off: a seam launch per step (round 4)")
     ap.add_argument("--diag", action="store_true", help="N = 8, rank 1 only: where the cost of the copy + hand-over lies")
     args = ap.parse_args()
     W, H, K = args.width, args.height, args.steps
@@ -54,6 +57,8 @@ def main():
     ctx.set_weights_blob(S.load_weights())
     if args.mode == "refbytes":
         ctx.set_mode(S.MODE_REFBYTES)
+    deferral = args.seam_deferral == "on" and args.mode == "mfma"
+    print(f"# seam deferral: {'on' if deferral else 'off'}")
     stream, side = torch.cuda.Stream(), torch.cuda.Stream()
     ctx.set_stream(stream.cuda_stream)
     d_plane = torch.from_numpy(plane).cuda()
@@ -62,6 +67,8 @@ def main():
     ctx.forward_y_dev(d_plane.data_ptr(), W, W * H, whole.data_ptr(), W, W * H, W, H, 1)
     ctx.synchronize()
     whole = whole.cpu().numpy()
+    if deferral:
+        ctx.set_seam_deferral(True)
 
     def timed(step, check=None):
         t0 = time.perf_counter()
@@ -75,6 +82,8 @@ def main():
             a.record(stream)
             for _ in range(K):
                 step()
+            if deferral:
+                ctx.flush()
             b.record(stream)
             torch.cuda.synchronize()
             best = min(best, a.elapsed_time(b) / K)
