@@ -38,6 +38,26 @@ int flush_seams(srcnn_ctx *c)
     return SRCNN_OK;
 }
 
+// May the seam blocks of the pending launch `a` run inside launch `b`'s kernel?  They write a's seam pixels while b's work items
+// write b's regular pixels: harmless when the two outputs are disjoint, and when b is the SAME launch again (same output, same
+// geometry, same work-item plan -- a step loop on one output buffer: b's own seam pixels are the ones a's blocks write, and b's
+// seam blocks rewrite them behind b).  Anything else that overlaps (another geometry into the same buffer) could let a stale
+// seam pixel of a land on a finished pixel of b: queue a's seam launch first.
+static bool fold_is_safe(const StripParams &a, const StripParams &b)
+{
+    auto span = [](const StripParams &q, const uint8_t **lo, size_t *bytes) {
+        *lo = q.dst + (long)(q.row_begin - q.dst_row0) * q.dst_stride;
+        *bytes = (size_t)(q.row_end - q.row_begin - 1) * (size_t)q.dst_stride + (size_t)q.width;
+    };
+    const uint8_t *alo, *blo;
+    size_t ab, bb;
+    span(a, &alo, &ab);
+    span(b, &blo, &bb);
+    if (!ranges_overlap(alo, ab, blo, bb)) return true;
+    return a.dst == b.dst && a.dst_stride == b.dst_stride && a.dst_row0 == b.dst_row0 && a.width == b.width && a.height == b.height &&
+           a.row_begin == b.row_begin && a.row_end == b.row_end && a.items == b.items && a.strips_total == b.strips_total;
+}
+
 // Common launch of the three strip modes on device memory.
 // fix_frame / fix_frames (SRCNN_MODE_REFBYTES only): this single-frame launch is frame `fix_frame` of a batch of `fix_frames`
 // whose flagged pixels ONE fix-up finishes, queued behind the batch's last launch (fix_frames = 1: the launch's own fix-up).
@@ -243,7 +263,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         if ((rc = flush_seams(c))) return rc;
         HIP_TRY(c, launch_split16(p, n_frames, c->stream, pad));
     }
-    else if (c->pending.valid && defer && c->pending.stream == c->stream && grid_items > 0) {
+    else if (c->pending.valid && defer && c->pending.stream == c->stream && grid_items > 0 && fold_is_safe(c->pending.f.prev, p)) {
         // the previous launch's seam blocks ride behind this launch's work items (srcnn_strip_fold_kernel)
         c->pending.f.first_block = grid_items;
         c->pending.valid = false;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SRCNN_MODE_REFBYTES with RANDOM MODELS (run on the GPU box; not part of pytest): the flag threshold follows the model
-(fixup_delta(): 6 * 2^-24 * ||W3||_2 * bound of the layer-2 map + 4 * 2^-24 * 256), so other weights must give the reference's
+(fixup_delta(): 4 * 2^-24 * ||W3||_2 * bound of the layer-2 map + 4 * 2^-24 * 256), so other weights must give the reference's
 bytes too, with the monitored deviation well inside the threshold -- in SRCNN_MODE_REFBYTES and, where the model fits the
 f16 ranges of that mode, in SRCNN_MODE_REFBYTES16.  usage: python tests/checks/soak_models.py [seconds] [seed]"""
 import sys, time
@@ -12,7 +12,7 @@ from srcnn_cpp_amd.synth import synth_luma
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
-n, n16, worst, worst16, t0 = 0, 0, 0.0, 0.0, time.time()
+n, n16, worst, worst16, reruns, t0 = 0, 0, 0.0, 0.0, 0, time.time()
 while time.time() - t0 < budget:
     s1, s2, s3 = rng.uniform(0.03, 0.25), rng.uniform(0.03, 0.4), rng.uniform(0.005, 0.08)
     w1 = (rng.standard_normal(5184) * s1).astype(np.float32)
@@ -42,11 +42,14 @@ while time.time() - t0 < budget:
             st = ctx.fixup_stats()
             assert np.array_equal(out, r_out), (mode, n, w, h, kind, s1, s2, s3, int((out != r_out).sum()), st)
             ratio = st["max_dev"] / st["delta"] if st["delta"] > 0 else 0.0
-            assert ratio < 0.5, (mode, n, st, s1, s2, s3)
+            # above delta / 2 the device-side net must have redone the launch (the bytes above are already checked)
+            assert ratio < 0.5 or st["exact_reruns"] >= 1, (mode, n, st, s1, s2, s3)
+            reruns += int(st["exact_reruns"] >= 1)
             if mode == S.MODE_REFBYTES:
                 worst = max(worst, ratio)
             else:
                 worst16, n16 = max(worst16, ratio), n16 + 1
     n += 1
 print(f"soak_models ok: {n} random models x planes in {time.time() - t0:.0f} s ({n16} of them also in REFBYTES16); every plane bytewise equal "
-      f"to the reference arithmetic; largest monitored deviation / threshold = {worst:.3f} (REFBYTES16: {worst16:.3f})")
+      f"to the reference arithmetic; largest monitored deviation / threshold = {worst:.3f} (REFBYTES16: {worst16:.3f}); "
+      f"{reruns} launches were over delta / 2 and redone by the device-side net")

@@ -158,3 +158,23 @@ def test_full_size_planes_with_deferral(ctx):
     ctx.flush()
     ctx.synchronize()
     assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == pin["gpuorder_sha256"][0]
+
+
+def test_overlapping_outputs_of_different_launches_are_not_folded(ctx, weights_blob):
+    """A deferred launch's seam blocks write ITS seam pixels while the next launch's work items run.  When the next launch writes
+    another geometry into the same buffer (here: rows 200..899 of a second plane over the first plane's output) a stale seam
+    pixel could land on a finished pixel -- the library queues the pending seam launch first instead of folding it in."""
+    import torch
+    w, h = 1920, 1080
+    a, b = synth_luma(w, h, frame=1), synth_luma(w, h, frame=9)
+    want_a, want_b = (oracle.gpuorder_forward_y(p, weights_blob)[0] for p in (a, b))
+    d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    d_out = torch.zeros_like(d_a)
+    torch.cuda.synchronize()
+    ctx.set_seam_deferral(True)
+    ctx.forward_y_dev(d_a.data_ptr(), w, 0, d_out.data_ptr(), w, 0, w, h, 1)
+    ctx.forward_y_rows_dev(d_b[194:906].data_ptr(), w, 194, d_out.data_ptr(), w, 0, w, h, 200, 900)
+    ctx.flush()
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[200:900], want_b[200:900]) and np.array_equal(got[:200], want_a[:200]) and np.array_equal(got[900:], want_a[900:])

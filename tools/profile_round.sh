@@ -16,6 +16,7 @@ export TMPDIR=/tmp
 if [ -z "$PMC_ONLY" ]; then
 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_line.json 2>> $OUT/bench_default.err      # the driver's exact command
+python bench.py --steps 20 --warmup 5 --seam-deferral off > $OUT/bench_driver_line_no_deferral.json 2>> $OUT/bench_default.err
 python bench.py --mode refbytes --no-cpu-baseline > $OUT/bench_refbytes.json 2>> $OUT/bench_default.err
 python bench.py --mode refbytes --frames 64 --steps 5 --no-cpu-baseline > $OUT/bench_refbytes_b64.json 2>> $OUT/bench_default.err
 python bench.py --mode refbytes16 --no-cpu-baseline > $OUT/bench_refbytes16.json 2>> $OUT/bench_default.err
@@ -53,8 +54,11 @@ python tools/evt_test.py > $OUT/clock_ramp.txt 2>&1
 python tools/diag_split16.py > $OUT/diag_stamps_split16.txt 2>&1
 tools/stripe_overhead.sh $OUT/stripe_overhead.txt > /dev/null 2>&1
 python tools/stripe_projection.py > $OUT/stripe_projection.txt 2>&1
-python tools/stripe_projection.py --diag > $OUT/stripe_projection_diag.txt 2>&1
+python tools/stripe_projection.py --seam-deferral off > $OUT/stripe_projection_no_deferral.txt 2>&1
 python tools/stripe_projection.py --mode refbytes --ns 1,8 > $OUT/stripe_projection_refbytes.txt 2>&1
+python tests/checks/time_cli.py 7 > $OUT/cli_process_cold.txt 2>&1
+tools/ab_refbytes.sh $OUT/fix_apply_ab_final.txt > /dev/null 2>&1
+tools/ab_defer.sh > $OUT/seam_deferral_ab_final.txt 2>&1
 python tests/checks/soak.py 120 31 > $OUT/soak.txt 2>&1
 python tests/checks/soak_paths.py 60 37 > $OUT/soak_paths.txt 2>&1
 python tests/checks/soak_models.py 240 3 > $OUT/soak_models.txt 2>&1
