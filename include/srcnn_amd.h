@@ -73,7 +73,7 @@ enum {
  *   SRCNN_MODE_REFBYTES the reference's BYTES at nearly the MFMA speed: the fused forward pass
  *                    (srcnn_forward_y*, row stripes, srcnn_process_bgr*) runs the float32 MFMA kernel, which
  *                    also marks every pixel whose pre-truncation value lies within delta of an
- *                    integer (~0.3 % of them; delta is derived from the model, DESIGN.md section 4.4), and
+ *                    integer (~0.3 % of them; delta is derived from the model, DESIGN.md section 4.3), and
  *                    exactly those pixels are then recomputed in the reference's arithmetic
  *                    (src/srcnn.cpp:238-240 truncates: only there can rounding noise change a byte).
  *                    The recomputation measures how far the MFMA values were off; a launch where that
@@ -238,6 +238,17 @@ int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx,
 int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx,
                             const uint8_t *src, size_t src_stride,
                             uint8_t *dst, size_t dst_stride, int width, int height);
+
+/* A STREAM of n_planes host planes, each row-striped over the contexts, as a pipeline: while the kernels of plane p run, every
+ * context's rows of plane p + 1 are on their way up and its rows of plane p - 1 on their way back (two stripe buffers and two
+ * copy streams per context; what must be ordered across contexts -- a launch reads its neighbours' edge rows, an upload
+ * overwrites rows a neighbour's launch read -- goes through events, not through the host).  Returns when every dst[p] is
+ * complete; bit-identical to srcnn_forward_y on each plane.  Links without peer access and the split-f16 modes run plane by
+ * plane through srcnn_forward_y_striped. */
+int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx,
+                                   const uint8_t *const *src, size_t src_stride,
+                                   uint8_t *const *dst, size_t dst_stride,
+                                   int width, int height, int n_planes);
 
 /* Same on device memory: d_stripes[k] / d_out[k] are DEVICE pointers on
  * ctxs[k]'s GPU to that context's rows of the input / output plane.  The inputs

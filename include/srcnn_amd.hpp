@@ -86,14 +86,18 @@ public:
         thread_local Session s(0);
         return s;
     }
-    // The reference's BYTES from the MFMA path (SRCNN_MODE_REFBYTES, srcnn_amd.h): `strict` makes the library act on its own
-    // monitor -- a launch whose measured rounding noise comes within a factor two of the flag threshold is redone on the
-    // exact kernels -- at the price of one host synchronisation per launch.
-    void reference_bytes(bool on = true, bool strict = false)
+    // The reference's BYTES from the MFMA path (SRCNN_MODE_REFBYTES, srcnn_amd.h).  `net` (on by default, as in the C ABI): the
+    // library acts on its own monitor -- a launch whose measured rounding noise comes within a factor two of the flag threshold
+    // is redone in the reference's arithmetic on every pixel, on the device, without a host read (srcnn_set_fixup_strict).
+    void reference_bytes(bool on = true, bool net = true)
     {
         check(srcnn_set_mode(get(), on ? SRCNN_MODE_REFBYTES : SRCNN_MODE_MFMA));
-        check(srcnn_set_fixup_strict(get(), strict ? 1 : 0));
+        check(srcnn_set_fixup_strict(get(), net ? 1 : 0));
     }
+    // Seam deferral for callers that queue launches back to back on one stream (srcnn_set_seam_deferral): the last launch's
+    // output is complete after flush() or any other call on the session.
+    void seam_deferral(bool on = true) { check(srcnn_set_seam_deferral(get(), on ? 1 : 0)); }
+    void flush() { check(srcnn_flush(get())); }
     // 0: the fast strip kernels (their hardware interlock was verified on this device at creation), 1: the hazard-safe ones
     int kernel_variant() const { return srcnn_kernel_variant(get()); }
 
@@ -341,6 +345,26 @@ inline void ForwardYFrames(SessionSet &set, std::vector<MatU8> &src, std::vector
     }
     set.check(srcnn_forward_y_frames_multi(set.data(), set.size(), in.data(), detail::stride<std::uint8_t>(src[0]), out.data(),
                                            detail::stride<std::uint8_t>(dst[0]), src[0].cols, src[0].rows, (int)src.size()));
+}
+
+// A stream of equally sized LARGE planes, each row-striped over the GPUs of the set, pipelined: uploads, kernels and downloads
+// of neighbouring planes overlap, ordered across GPUs by events (srcnn_forward_y_striped_frames).
+template <class MatU8>
+inline void ForwardYStripedFrames(SessionSet &set, std::vector<MatU8> &src, std::vector<MatU8> &dst)
+{
+    if (src.empty() || src.size() != dst.size()) throw Error(SRCNN_ERR_INVALID, "ForwardYStripedFrames: need as many outputs as inputs");
+    std::vector<const std::uint8_t *> in(src.size());
+    std::vector<std::uint8_t *> out(src.size());
+    for (std::size_t i = 0; i < src.size(); ++i) {
+        if (src[i].rows != src[0].rows || src[i].cols != src[0].cols || dst[i].rows != src[0].rows || dst[i].cols != src[0].cols ||
+            detail::stride<std::uint8_t>(src[i]) != detail::stride<std::uint8_t>(src[0]) ||
+            detail::stride<std::uint8_t>(dst[i]) != detail::stride<std::uint8_t>(dst[0]))
+            throw Error(SRCNN_ERR_INVALID, "ForwardYStripedFrames: planes must share size and row stride");
+        in[i] = detail::ptr<const std::uint8_t>(src[i]);
+        out[i] = detail::ptr<std::uint8_t>(dst[i]);
+    }
+    set.check(srcnn_forward_y_striped_frames(set.data(), set.size(), in.data(), detail::stride<std::uint8_t>(src[0]), out.data(),
+                                             detail::stride<std::uint8_t>(dst[0]), src[0].cols, src[0].rows, (int)src.size()));
 }
 
 // The timed region of the reference's pipeline driver (src/srcnn.cpp:505-659) with the

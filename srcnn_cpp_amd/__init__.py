@@ -26,7 +26,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 __all__ = [
-    "Context", "SrcnnError", "load_library", "library_path", "tuning_library_path", "use_library", "load_weights", "split_weights",
+    "Context", "SrcnnError", "forward_y_striped_frames", "load_library", "library_path", "tuning_library_path", "use_library", "load_weights", "split_weights",
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
     "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "MODE_REFBYTES16", "FLOP_PER_PIXEL",
     "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
@@ -147,6 +147,7 @@ def load_library() -> C.CDLL:
         "srcnn_stripe_rows": ([i, i, i, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_forward_y_frames_multi": ([C.POINTER(vp), i, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
         "srcnn_forward_y_striped": ([C.POINTER(vp), i, _u8p, sz, _u8p, sz, i, i], i),
+        "srcnn_forward_y_striped_frames": ([C.POINTER(vp), i, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
         "srcnn_forward_y_striped_dev": ([C.POINTER(vp), i, C.POINTER(vp), sz, C.POINTER(vp), sz, i, i], i),
     }
     for name, (args, res) in sigs.items():
@@ -166,7 +167,7 @@ ABI_SYMBOLS = (
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
     "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_set_seam_deferral", "srcnn_flush", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
-    "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_dev",
+    "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_frames", "srcnn_forward_y_striped_dev",
 )
 
 
@@ -599,6 +600,22 @@ def forward_y_striped(ctxs: Sequence[Context], src, dst=None):
     ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_striped(_ctx_array(ctxs), len(ctxs), src.ctypes.data_as(_u8p),
                                                                      ss, dst.ctypes.data_as(_u8p), ds, w, h))
     return dst
+
+
+def forward_y_striped_frames(ctxs: Sequence[Context], planes, out=None):
+    """A STREAM of host planes [n, h, w], each row-striped over the contexts, pipelined (srcnn_forward_y_striped_frames)."""
+    if not isinstance(planes, np.ndarray) or planes.dtype != np.uint8 or planes.ndim != 3 or not planes.flags.c_contiguous:
+        raise ValueError("planes: expected a C-contiguous [n, h, w] uint8 array")
+    n, h, w = planes.shape
+    if out is None:
+        out = np.empty_like(planes)
+    _same_shape("out", out.shape, planes.shape)
+    if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or not out.flags.c_contiguous or not out.flags.writeable:
+        raise ValueError("out: must be a C-contiguous writeable uint8 array")
+    srcs = (_u8p * n)(*[planes[k].ctypes.data_as(_u8p) for k in range(n)])
+    dsts = (_u8p * n)(*[out[k].ctypes.data_as(_u8p) for k in range(n)])
+    ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_striped_frames(_ctx_array(ctxs), len(ctxs), srcs, w, dsts, w, w, h, n))
+    return out
 
 
 def forward_y_striped_dev(ctxs: Sequence[Context], d_stripes, stripe_stride, d_out, out_stride, width, height):

@@ -137,6 +137,8 @@ void srcnn_destroy(srcnn_ctx *c)
         release(t.dev_winmap);
     }
     for (int k = 0; k < 2; ++k) {
+        for (hipEvent_t e : {c->sf_up[k], c->sf_k[k], c->sf_down[k]})
+            if (e) (void)hipEventDestroy(e);
         release(c->lane_in[k]);
         release(c->lane_out[k]);
         if (c->pin_in[k]) (void)hipHostFree(c->pin_in[k]);

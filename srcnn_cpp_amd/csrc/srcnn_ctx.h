@@ -11,6 +11,7 @@
 #include "srcnn_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -203,6 +204,11 @@ struct srcnn_ctx {
     unsigned long stripe_steps = 0;
     int halo_transport = 0;                // srcnn_halo_transport(): 0 none yet, 1 same device, 2 peer access (xGMI), 3 staged by the runtime
     std::vector<int> peer_state;           // per device id: 0 not asked yet, 2 peer access enabled, 3 refused
+    // pipeline of a row-striped STREAM of planes (srcnn_forward_y_striped_frames): events behind the upload / the kernel / the
+    // download of the plane in buffer b, and how many planes' events have been RECORDED so far -- a stream may only be told to
+    // wait for an event another host thread has already recorded
+    hipEvent_t sf_up[2] = {nullptr, nullptr}, sf_k[2] = {nullptr, nullptr}, sf_down[2] = {nullptr, nullptr};
+    std::atomic<int> sf_gen_up{0}, sf_gen_k{0}, sf_abort{0};
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     srcnn::host::DevBuf lane_in[2], lane_out[2];
     void *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};   // pinned host staging
@@ -211,6 +217,7 @@ struct srcnn_ctx {
     // next such launch on the same stream carries its blocks (srcnn_strip_fold_kernel), anything else on the context queues it
     // first (flush_seams(): every entry point through BIND, the item-table eviction, srcnn_flush, srcnn_destroy).
     bool defer_seams = false;
+    int defer_block = 0;                   // > 0: inside an entry point that uses the device launches itself and reads their output (no deferral)
     struct PendingSeams {
         bool valid = false;
         hipStream_t stream = nullptr;
@@ -258,13 +265,23 @@ struct DeviceScope {
     DeviceScope(const DeviceScope &) = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
+// While an entry point that calls the device launches ITSELF runs (host-buffer paths, the frame pipeline, the several-GPU calls:
+// they read the launches' output right behind them), seam deferral is off: it is a contract with the DIRECT caller of a launch.
+struct DeferBlock {
+    srcnn_ctx *c;
+    explicit DeferBlock(srcnn_ctx *ctx) : c(ctx) { ++c->defer_block; }
+    ~DeferBlock() { --c->defer_block; }
+    DeferBlock(const DeferBlock &) = delete;
+    DeferBlock &operator=(const DeferBlock &) = delete;
+};
 // BIND_KEEP: the entry points whose launch can CARRY deferred seam work (run_strip decides); BIND: everything else queues it first.
 #define BIND_KEEP(c)            \
     DeviceScope dev_scope_(c);  \
     if (dev_scope_.rc) return dev_scope_.rc
 #define BIND(c)                                                        \
     BIND_KEEP(c);                                                      \
-    if (int flush_rc_ = srcnn::host::flush_seams(c)) return flush_rc_
+    if (int flush_rc_ = srcnn::host::flush_seams(c)) return flush_rc_; \
+    srcnn::host::DeferBlock defer_block_(c)
 
 int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes);
 void release(DevBuf &b);
@@ -326,6 +343,7 @@ int flush_seams(srcnn_ctx *c);
 
 // ---- srcnn_host.cpp ----
 void cubic_table(int n_src, int n_dst, int *ofs, short *coef);
+int ensure_lanes(srcnn_ctx *c, size_t bytes);      // the two lane streams, lane_in / lane_out device buffers and pinned staging of >= bytes
 
 // rows of `width` elements between a packed buffer and a strided one, split over a few threads
 template <typename T>

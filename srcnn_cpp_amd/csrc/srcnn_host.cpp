@@ -186,6 +186,40 @@ extern "C" {
 
 /* ------------------------- host-buffer entry points ------------------------- */
 
+}  // extern "C"
+
+namespace srcnn {
+namespace host {
+
+int ensure_lanes(srcnn_ctx *c, size_t n)
+{
+    int rc;
+    for (int k = 0; k < 2; ++k) {
+        if (!c->lane_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+        if ((rc = reserve(c, c->lane_in[k], n))) return rc;
+        if ((rc = reserve(c, c->lane_out[k], n))) return rc;
+    }
+    if (c->pin_cap < n) {       // pinned staging: copies from/to pageable memory would serialise the lanes
+        for (int k = 0; k < 2; ++k) {
+            if (c->pin_in[k]) (void)hipHostFree(c->pin_in[k]);
+            if (c->pin_out[k]) (void)hipHostFree(c->pin_out[k]);
+            c->pin_in[k] = c->pin_out[k] = nullptr;
+        }
+        c->pin_cap = 0;
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(c, hipHostMalloc(&c->pin_in[k], n, hipHostMallocDefault));
+            HIP_TRY(c, hipHostMalloc(&c->pin_out[k], n, hipHostMallocDefault));
+        }
+        c->pin_cap = n;
+    }
+    return SRCNN_OK;
+}
+
+}  // namespace host
+}  // namespace srcnn
+
+extern "C" {
+
 /* A stream of host frames (BASELINE configs[4] shape): two lanes, each with its own HIP stream and
  * device buffers, alternate, so frame i+1's upload and frame i-1's download run while frame i's
  * kernel computes -- the PCIe transfers hide behind the MFMA-bound kernel. */
@@ -209,24 +243,7 @@ int srcnn_forward_y_frames(srcnn_ctx *c, const uint8_t *const *src, size_t src_s
     }
     const size_t n = (size_t)width * height;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 2; ++k) {
-        if (!c->lane_stream[k]) HIP_TRY(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
-        if ((rc = reserve(c, c->lane_in[k], n))) return rc;
-        if ((rc = reserve(c, c->lane_out[k], n))) return rc;
-    }
-    if (c->pin_cap < n) {       // pinned staging: copies from/to pageable memory would serialise the lanes
-        for (int k = 0; k < 2; ++k) {
-            if (c->pin_in[k]) (void)hipHostFree(c->pin_in[k]);
-            if (c->pin_out[k]) (void)hipHostFree(c->pin_out[k]);
-            c->pin_in[k] = c->pin_out[k] = nullptr;
-        }
-        c->pin_cap = 0;
-        for (int k = 0; k < 2; ++k) {
-            HIP_TRY(c, hipHostMalloc(&c->pin_in[k], n, hipHostMallocDefault));
-            HIP_TRY(c, hipHostMalloc(&c->pin_out[k], n, hipHostMallocDefault));
-        }
-        c->pin_cap = n;
-    }
+    if ((rc = ensure_lanes(c, n))) return rc;
     hipStream_t caller = c->stream;
     // (between the caller's pageable memory and the pinned staging on a few host threads: one thread moves 16.6 MB per
     // 3840x2160 frame -- in and out -- in about the time the kernel takes, and the stream becomes host-bound)

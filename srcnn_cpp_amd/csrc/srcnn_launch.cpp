@@ -166,7 +166,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
                 sc->stream = c->stream;
                 // Seam deferral: this launch's seam blocks will ride behind the NEXT launch's work items, which writes its own
                 // exports meanwhile -- the two scratch sets of the stream are used in turn.
-                defer = may_defer && c->defer_seams && !c->safe_hazards && fused32 && n_frames == 1 && !p.pre && !(p.tune & 16) &&
+                defer = may_defer && c->defer_seams && c->defer_block == 0 && !c->safe_hazards && fused32 && n_frames == 1 && !p.pre && !(p.tune & 16) &&
                         table->separated && table->n_seams > 0 && col_seams &&
                         !(c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16);
                 if (defer) sc->flip ^= 1;
@@ -568,6 +568,15 @@ int srcnn_forward_y_rows_halo_dev(srcnn_ctx *c, const uint8_t *d_src, size_t src
                                           "the halo buffers 6 rows either side", row_begin, row_end, need0, need1, src_row0, src_row1);
     if (c->mode != SRCNN_MODE_MFMA && c->mode != SRCNN_MODE_REFBYTES)
         return fail(c, SRCNN_ERR_STATE, "separate halo buffers are read by the float32 MFMA kernel only (SRCNN_MODE_MFMA / REFBYTES)");
+    {   // like srcnn_forward_y_dev: the path cannot run in place -- the rows written must overlap none of the rows read
+        const uint8_t *out0 = d_dst + (size_t)(row_begin - dst_row0) * dst_stride;
+        const size_t out_bytes = (size_t)(row_end - row_begin - 1) * dst_stride + (size_t)width;
+        const size_t halo_bytes = (size_t)(kHaloRows - 1) * halo_stride + (size_t)width;
+        if (ranges_overlap(out0, out_bytes, d_src, (size_t)(src_rows - 1) * src_stride + (size_t)width) ||
+            (d_halo_top && ranges_overlap(out0, out_bytes, d_halo_top, halo_bytes)) ||
+            (d_halo_bot && ranges_overlap(out0, out_bytes, d_halo_bot, halo_bytes)))
+            return fail(c, SRCNN_ERR_INVALID, "forward_y_rows_halo_dev: the output rows overlap the input (src or a halo buffer)");
+    }
     StripParams p{};
     p.src = d_src;
     p.src_stride = (long)src_stride;

@@ -271,6 +271,129 @@ int srcnn_forward_y_striped(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *sr
     });
 }
 
+/* A STREAM of planes, each row-striped over the contexts: a pipeline, not n_planes one-shot calls.  Context k keeps two stripe
+ * buffers; while the kernels of plane p run, its rows of plane p + 1 go up on a copy stream of their own and its rows of plane
+ * p - 1 come back on another.  What has to be ordered ACROSS contexts goes through events, never through the host: the launch
+ * of plane p on context k waits for the uploads of plane p on k - 1, k, k + 1 (it reads their edge rows where they lie), and
+ * the upload of plane p + 2 into the buffer plane p used waits for the kernels of plane p on k - 1, k, k + 1 (theirs read its
+ * edge rows).  One host thread per context; a thread tells a stream to wait for another context's event only once that event
+ * has been RECORDED (the contexts' generation counters), and spins for nothing else. */
+int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *src, size_t src_stride,
+                                   uint8_t *const *dst, size_t dst_stride, int width, int height, int n_planes)
+{
+    int rc = check_ctx_set(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!src || !dst || n_planes <= 0 || width <= 0 || height <= 0 || src_stride < (size_t)width || dst_stride < (size_t)width)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_frames: bad arguments");
+    for (int p = 0; p < n_planes; ++p)
+        if (!src[p] || !dst[p]) return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_frames: null plane %d", p);
+    if (n_ctx > 1 && height / n_ctx < kHalo)
+        return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_striped_frames: stripes thinner than the %d-row halo", kHalo);
+    // set-up on every context: lanes, events, links; the pipeline needs the one-launch form (float32 MFMA kernel, neighbours'
+    // rows readable where they lie)
+    bool one_launch = n_ctx > 1;
+    rc = run_per_context(ctxs, n_ctx, [&](int k) -> int {
+        srcnn_ctx *c = ctxs[k];
+        BIND(c);
+        int r, r0, r1;
+        srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
+        if ((r = ensure_lanes(c, (size_t)(r1 - r0) * width))) return r;
+        for (int b = 0; b < 2; ++b)
+            for (hipEvent_t *e : {&c->sf_up[b], &c->sf_k[b], &c->sf_down[b]})
+                if (!*e) HIP_TRY(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        c->sf_gen_up.store(0);
+        c->sf_gen_k.store(0);
+        c->sf_abort.store(0);
+        if (n_ctx > 1 && (r = stripe_setup(ctxs, n_ctx, k))) return r;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return SRCNN_OK;
+    });
+    if (rc) return rc;
+    for (int k = 0; k < n_ctx; ++k)
+        if (ctxs[k]->halo_transport == 3 || (ctxs[k]->mode != SRCNN_MODE_MFMA && ctxs[k]->mode != SRCNN_MODE_REFBYTES)) one_launch = false;
+    if (!one_launch) {          // one context, a link without peer access, the split-f16 modes: plane by plane
+        for (int p = 0; p < n_planes; ++p)
+            if ((rc = srcnn_forward_y_striped(ctxs, n_ctx, src[p], src_stride, dst[p], dst_stride, width, height))) return rc;
+        return SRCNN_OK;
+    }
+    auto aborted = [&] {
+        for (int k = 0; k < n_ctx; ++k)
+            if (ctxs[k]->sf_abort.load(std::memory_order_acquire)) return true;
+        return false;
+    };
+    return run_per_context(ctxs, n_ctx, [&](int k) -> int {
+        srcnn_ctx *c = ctxs[k];
+        BIND(c);
+        int r0, r1, a0 = 0, a1 = 0;
+        srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
+        if (k > 0) srcnn_stripe_rows(height, n_ctx, k - 1, &a0, &a1);
+        const int rows = r1 - r0;
+        const size_t n = (size_t)rows * width;
+        hipStream_t up = c->lane_stream[0], down = c->lane_stream[1];
+        const int nb[3] = {k - 1, k, k + 1};
+        // spin until context j has RECORDED its event of plane `want - 1`; false = some context gave up
+        auto recorded = [&](const std::atomic<int> &gen, int want) {
+            while (gen.load(std::memory_order_acquire) < want) {
+                if (aborted()) return false;
+                std::this_thread::yield();
+            }
+            return true;
+        };
+        auto body = [&]() -> int {
+            int r;
+            for (int p = 0; p <= n_planes; ++p) {
+                const int b = p & 1;
+                if (p < n_planes) {
+                    if (p >= 2) {
+                        // buffer b held plane p - 2: its readers (this context's kernel and the neighbours') must be done, and
+                        // the pinned staging must have left for the device
+                        for (int j : nb) {
+                            if (j < 0 || j >= n_ctx) continue;
+                            if (!recorded(ctxs[j]->sf_gen_k, p - 1)) return SRCNN_ERR_STATE;
+                            HIP_TRY(c, hipStreamWaitEvent(up, ctxs[j]->sf_k[b], 0));
+                        }
+                        HIP_TRY(c, hipEventSynchronize(c->sf_up[b]));
+                    }
+                    copy_rows_mt<uint8_t>(static_cast<uint8_t *>(c->pin_in[b]), (size_t)width, src[p] + (size_t)r0 * src_stride, src_stride, width, rows);
+                    HIP_TRY(c, hipMemcpyAsync(c->lane_in[b].p, c->pin_in[b], n, hipMemcpyHostToDevice, up));
+                    HIP_TRY(c, hipEventRecord(c->sf_up[b], up));
+                    c->sf_gen_up.store(p + 1, std::memory_order_release);
+                    // the launch: behind the uploads of plane p on the three contexts whose rows it reads, and behind the download of
+                    // plane p - 2 from the output buffer it writes
+                    for (int j : nb) {
+                        if (j < 0 || j >= n_ctx) continue;
+                        if (!recorded(ctxs[j]->sf_gen_up, p + 1)) return SRCNN_ERR_STATE;
+                        HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[j]->sf_up[b], 0));
+                    }
+                    if (p >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->sf_down[b], 0));
+                    const uint8_t *top = k > 0 ? static_cast<const uint8_t *>(ctxs[k - 1]->lane_in[b].p) + (size_t)(a1 - a0 - kHalo) * width : nullptr;
+                    const uint8_t *bot = k < n_ctx - 1 ? static_cast<const uint8_t *>(ctxs[k + 1]->lane_in[b].p) : nullptr;
+                    if ((r = srcnn_forward_y_rows_halo_dev(c, static_cast<const uint8_t *>(c->lane_in[b].p), (size_t)width, r0, rows, top, bot, (size_t)width,
+                                                           static_cast<uint8_t *>(c->lane_out[b].p), (size_t)width, r0, width, height, r0, r1)))
+                        return r;
+                    HIP_TRY(c, hipEventRecord(c->sf_k[b], c->stream));
+                    c->sf_gen_k.store(p + 1, std::memory_order_release);
+                    HIP_TRY(c, hipStreamWaitEvent(down, c->sf_k[b], 0));
+                    HIP_TRY(c, hipMemcpyAsync(c->pin_out[b], c->lane_out[b].p, n, hipMemcpyDeviceToHost, down));
+                    HIP_TRY(c, hipEventRecord(c->sf_down[b], down));
+                }
+                if (p >= 1) {       // hand plane p - 1 to the caller while plane p computes
+                    const int q = (p - 1) & 1;
+                    HIP_TRY(c, hipEventSynchronize(c->sf_down[q]));
+                    copy_rows_mt<uint8_t>(dst[p - 1] + (size_t)r0 * dst_stride, dst_stride, static_cast<const uint8_t *>(c->pin_out[q]), (size_t)width, width, rows);
+                }
+            }
+            return SRCNN_OK;
+        };
+        const int r = body();
+        if (r) c->sf_abort.store(1, std::memory_order_release);       // the others stop waiting for this context's events
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(up);
+        (void)hipStreamSynchronize(down);
+        return r;
+    });
+}
+
 int srcnn_halo_transport(const srcnn_ctx *c) { return c ? c->halo_transport : SRCNN_ERR_INVALID; }
 
 int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *src, size_t src_stride,

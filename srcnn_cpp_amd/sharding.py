@@ -398,12 +398,18 @@ class PeerStripeStep:
     the stripe's edges (``srcnn_forward_y_rows_halo_dev`` takes the mapped addresses as its halo pointers).  What the one-process
     host does with peer access (``srcnn_forward_y_striped_dev``), for one process per GPU.
 
-    The stripe lives in an allocation of its own (``Context.dev_alloc``: an IPC handle names a whole allocation); ``upload()``
-    refills it.  A neighbour READS this rank's edge rows during its step, so a new plane may be uploaded only after every
-    rank has finished the step on the old one (``barrier()``); the bench's input is resident and constant.
+    STREAMS OF PLANES.  The stripe lives in TWO allocations of its own used in turn (``Context.dev_alloc``: an IPC handle names a
+    whole allocation; both are exported and mapped once).  ``upload(rows)`` writes plane g into allocation g % 2 -- the one no
+    neighbour's step on plane g - 1 reads -- through a second context, so the copy does not queue behind the kernels; ``step()``
+    runs the latest plane.  What has to be ordered ACROSS ranks is settled neighbour to neighbour, not by a barrier: a rank tells
+    its two neighbours "plane g is uploaded" after the copy and waits for theirs before the first step on plane g (their edge
+    rows are read by its launch); before it overwrites allocation g % 2 it tells them "my steps on plane g - 2 are done" and waits
+    for theirs (their launches read its edge rows).  One-word gloo messages with tags; a plane stepped repeatedly (the bench's
+    resident input) exchanges nothing after its first step.
     """
 
     def __init__(self, ctx, stripe_rows_np, out, height: int, world: int, rank: int, group=None):
+        import torch
         import torch.distributed as dist
 
         self.ctx, self.out, self.height, self.world, self.rank, self.group = ctx, out, height, world, rank, group
@@ -413,48 +419,94 @@ class PeerStripeStep:
             raise ValueError(f"rank {rank}: stripe has {stripe_rows_np.shape[0]} rows, owns [{self.r0},{self.r1})")
         if world > 1 and min(b - a for a, b in (stripe_rows(height, world, k) for k in range(world))) < HALO_ROWS:
             raise ValueError("stripes thinner than the halo: use fewer ranks for this plane")
-        self.d_stripe = ctx.dev_alloc((self.r1 - self.r0) * self.width)
-        self.upload(stripe_rows_np)
-        self.top = self.bot = 0
-        self._mapped = []
+        nbytes = (self.r1 - self.r0) * self.width
+        self.d_stripes = [ctx.dev_alloc(nbytes), ctx.dev_alloc(nbytes)]
+        self.d_stripe = self.d_stripes[0]                  # (the allocation of the plane being stepped; kept for older callers)
+        self.top, self.bot = [0, 0], [0, 0]
+        self._mapped, self._sends, self._copy_ctx = [], [], None
+        self.nbrs = [n for n in (rank - 1, rank + 1) if 0 <= n < world]
+        self.gen, self._ready_seen = 0, -1                 # planes uploaded so far; the last plane whose neighbours are known ready
+        self._done_ev = [None, None]                       # behind this rank's last step on the plane in allocation b
+        self._done_sent = -1
+        self._torch, self._dist = torch, dist
         if world > 1:
             # Collective-safe: a rank whose export / mapping fails (no IPC between these two devices, a runtime without dmabuf
             # IPC) must not leave the others waiting in a collective -- every rank reports, then all succeed or all raise.
             err, handle = None, None
             try:
-                handle = ctx.ipc_export(self.d_stripe)
+                handle = [ctx.ipc_export(d) for d in self.d_stripes]
             except Exception as e:          # noqa: BLE001 -- reported to every rank below
                 err = f"rank {rank}: export: {e}"
             handles = [None] * world
             dist.all_gather_object(handles, (handle, err), group=group)
             if all(h[1] is None for h in handles):
                 try:
-                    if rank > 0:
-                        a0, a1 = stripe_rows(height, world, rank - 1)
-                        base = ctx.ipc_open(handles[rank - 1][0])
-                        self._mapped.append(base)
-                        self.top = base + (a1 - a0 - HALO_ROWS) * self.width          # the upper neighbour's last 6 rows
-                    if rank < world - 1:
-                        base = ctx.ipc_open(handles[rank + 1][0])
-                        self._mapped.append(base)
-                        self.bot = base                                                # the lower neighbour's first 6 rows
+                    for b in range(2):
+                        if rank > 0:
+                            a0, a1 = stripe_rows(height, world, rank - 1)
+                            base = ctx.ipc_open(handles[rank - 1][0][b])
+                            self._mapped.append(base)
+                            self.top[b] = base + (a1 - a0 - HALO_ROWS) * self.width      # the upper neighbour's last 6 rows
+                        if rank < world - 1:
+                            base = ctx.ipc_open(handles[rank + 1][0][b])
+                            self._mapped.append(base)
+                            self.bot[b] = base                                            # the lower neighbour's first 6 rows
                 except Exception as e:      # noqa: BLE001
                     err = f"rank {rank}: open: {e}"
             errs = [None] * world
-            dist.all_gather_object(errs, err, group=group)     # (also: every stripe is uploaded before anybody's first step reads a neighbour's rows)
+            dist.all_gather_object(errs, err, group=group)
             bad = [e for e in errs if e] + [h[1] for h in handles if h[1]]
             if bad:
                 self.close(collective=False)
                 raise RuntimeError("HIP IPC mapping of the neighbours' stripes failed: " + "; ".join(sorted(set(bad))))
+        self.upload(stripe_rows_np)
+
+    # ---- neighbour-to-neighbour ordering (gloo, one word per message) ----
+    def _tell(self, kind: int, g: int):
+        for n in self.nbrs:
+            self._sends.append(self._dist.isend(self._torch.tensor([g], dtype=self._torch.int64), dst=n, group=self.group, tag=2 * g + kind))
+        self._sends = [w for w in self._sends if not w.is_completed()]
+
+    def _hear(self, kind: int, g: int):
+        for n in self.nbrs:
+            t = self._torch.zeros(1, dtype=self._torch.int64)
+            self._dist.recv(t, src=n, group=self.group, tag=2 * g + kind)
+            if int(t.item()) != g:
+                raise RuntimeError(f"rank {self.rank}: neighbour {n} answered plane {int(t.item())}, expected {g}")
 
     def upload(self, stripe_rows_np):
-        self.ctx.dev_upload(self.d_stripe, stripe_rows_np)
+        """This rank's rows of the NEXT plane, into the allocation no step in flight reads.  No barrier."""
+        import srcnn_cpp_amd as S
+        g = self.gen
+        b = g % 2
+        if self.world > 1 and g >= 2:
+            # allocation b held plane g - 2: this rank's steps on it must have run, and the neighbours' (they read its edge rows)
+            if self._done_ev[b] is not None:
+                self._done_ev[b].synchronize()
+            if self._done_sent < g - 2:
+                self._tell(1, g - 2)
+                self._done_sent = g - 2
+            self._hear(1, g - 2)
+        if self._copy_ctx is None:          # a context of its own for the copies: dev_upload waits for ITS stream only
+            self._copy_ctx = S.Context(self.ctx.device) if hasattr(self.ctx, "device") else self.ctx
+        self._copy_ctx.dev_upload(self.d_stripes[b], stripe_rows_np)
+        if self.world > 1:
+            self._tell(0, g)
+        self.gen = g + 1
+        self.d_stripe = self.d_stripes[b]
 
     def step(self):
-        """One step: ONE launch, asynchronous on the context's stream."""
+        """One step on the latest plane: ONE launch, asynchronous on the context's stream."""
+        g = self.gen - 1
+        b = g % 2
+        if self.world > 1 and self._ready_seen < g:
+            self._hear(0, g)                 # the neighbours' rows of plane g are in place (first step on this plane only)
+            self._ready_seen = g
         out, w = self.out, self.width
-        self.ctx.forward_y_rows_halo_dev(self.d_stripe, w, self.r0, self.r1 - self.r0, self.top, self.bot, w,
+        self.ctx.forward_y_rows_halo_dev(self.d_stripes[b], w, self.r0, self.r1 - self.r0, self.top[b], self.bot[b], w,
                                          out.data_ptr(), out.stride(0), self.r0, w, self.height, self.r0, self.r1)
+        if self.world > 1:
+            self._done_ev[b] = self._torch.cuda.current_stream().record_event()
         return out
 
     __call__ = step
@@ -462,6 +514,9 @@ class PeerStripeStep:
     def close(self, collective: bool = True):
         import torch.distributed as dist
         self.ctx.synchronize()
+        for wk in self._sends:
+            wk.wait()
+        self._sends = []
         collective = collective and self.world > 1
         if collective:
             dist.barrier(group=self.group)  # nobody reads this rank's rows any more
@@ -469,10 +524,15 @@ class PeerStripeStep:
             self.ctx.ipc_close(base)
         self._mapped = []
         if collective:
-            dist.barrier(group=self.group)  # every mapping of this rank's allocation is gone before it is freed
-        if self.d_stripe:
-            self.ctx.dev_free(self.d_stripe)
-            self.d_stripe = 0
+            dist.barrier(group=self.group)  # every mapping of this rank's allocations is gone before they are freed
+        for d in self.d_stripes:
+            if d:
+                self.ctx.dev_free(d)
+        self.d_stripes = [0, 0]
+        self.d_stripe = 0
+        if self._copy_ctx is not None and self._copy_ctx is not self.ctx:
+            self._copy_ctx.close()
+        self._copy_ctx = None
 
 
 def forward_striped_launch(stripe, out, height: int, world: int, rank: int, launch_rows: Callable,

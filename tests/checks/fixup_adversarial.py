@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Attack on the flag threshold of SRCNN_MODE_REFBYTES (CPU only; run in the build container, not part of pytest).
 
-SRCNN_MODE_REFBYTES returns the reference's bytes as long as |v_gpu - v_ref| <= delta on every pixel (DESIGN.md section 4.4;
+SRCNN_MODE_REFBYTES returns the reference's bytes as long as |v_gpu - v_ref| <= delta on every pixel (DESIGN.md section 4.3;
 delta = fixup_delta() of srcnn_cpp_amd/csrc).  Rounds 1-3 SAMPLED that difference (54 MPix of content: max 4.4e-4); this
 script SEARCHES for it: randomised coordinate ascent over the 169 bytes of a pixel's 13 x 13 receptive field
 (oracle/adversarial.c: both arithmetics for one pixel, each bit for bit what oracle/srcnn_gpuorder.c / srcnn_oracle.c

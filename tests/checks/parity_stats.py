@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Print the measured parity of the MFMA path against the reference arithmetic
-(oracle) on a full 3840x2160 synthetic frame -- the numbers DESIGN.md section 5 quotes."""
+(oracle) on a full 3840x2160 synthetic frame -- the numbers DESIGN.md section 6 quotes."""
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))

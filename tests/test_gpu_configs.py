@@ -28,7 +28,7 @@ TOL_PRE_ABS = 5e-3
 
 
 def check_against_reference(out, frame, blob):
-    """u8 within 1 LSB, only next to a truncation boundary, on <= 1e-3 of the pixels (DESIGN.md section 5)."""
+    """u8 within 1 LSB, only next to a truncation boundary, on <= 1e-3 of the pixels (DESIGN.md section 6)."""
     r_out, r_pre = oracle.forward_y(frame, blob)
     d = np.abs(out.astype(np.int16) - r_out.astype(np.int16))
     assert d.max() <= 1

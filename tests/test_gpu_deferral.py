@@ -178,3 +178,28 @@ def test_overlapping_outputs_of_different_launches_are_not_folded(ctx, weights_b
     ctx.synchronize()
     got = d_out.cpu().numpy()
     assert np.array_equal(got[200:900], want_b[200:900]) and np.array_equal(got[:200], want_a[:200]) and np.array_equal(got[900:], want_a[900:])
+
+
+def test_entry_points_that_read_their_own_launches_never_defer(ctx, weights_blob):
+    """Deferral is a contract with the DIRECT caller of a device launch.  The host-buffer paths, the two-lane frame stream, the
+    several-context calls and the BGR pipeline call those launches themselves and read the output right behind them: with
+    deferral switched on they must still return complete planes."""
+    ctx.set_seam_deferral(True)
+    frames = synth_batch(1920, 1080, 4, first_frame=5)
+    want = [oracle.gpuorder_forward_y(f, weights_blob)[0] for f in frames[:2]]
+    assert np.array_equal(ctx.forward_y(frames[0]), want[0])                      # row bands over srcnn_forward_y_rows_dev
+    streamed = ctx.forward_y_frames(frames)                                       # lanes over srcnn_forward_y_dev
+    assert np.array_equal(streamed[0], want[0]) and np.array_equal(streamed[1], want[1])
+    one = ctx.forward_y(frames[3])
+    assert np.array_equal(streamed[3], one)
+    fx = np.load(GOLD / "butterfly_bgr.npz")
+    plain = S.Context(0)
+    plain.set_weights_blob(weights_blob)
+    assert np.array_equal(ctx.process_bgr(fx["src_bgr"], 2.0), plain.process_bgr(fx["src_bgr"], 2.0))
+    others = [S.Context(0) for _ in range(2)]
+    for c in others:
+        c.set_weights_blob(weights_blob)
+        c.set_seam_deferral(True)
+    assert np.array_equal(S.forward_y_striped([ctx] + others, frames[2]), plain.forward_y(frames[2]))
+    for c in others + [plain]:
+        c.close()

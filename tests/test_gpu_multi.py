@@ -8,6 +8,7 @@ except the xGMI links themselves.
   contexts on cuda:0 against the single-context result, from Python and from a plain C++ host
   (tools/host_demo_multi.cpp)."""
 import json
+import os
 import subprocess
 import sys
 from pathlib import Path
@@ -316,3 +317,59 @@ def test_bench_frames_line_carries_the_striped_plane():
     assert st["degraded"] is True and any("shared" in w for w in st["degraded_why"])       # two ranks on one GPU is a smoke configuration
     off = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--steps", 3, "--no-stripe-leg")
     assert "stripe" not in off
+
+
+def test_peer_stripes_stream_planes_without_a_barrier(gpu_ctx, tmp_path):
+    """`sharding.PeerStripeStep` streams NEW planes without a barrier per plane -- two stripe allocations per
+    rank used in turn (both mapped by the neighbours once), `upload(k + 1)` while plane k computes, and only neighbour-to-
+    neighbour handshakes ("uploaded" / "done with it") over gloo.  Three processes share cuda:0 and stream 8 different
+    1920x1080 planes; every plane stitched from their rows equals the single-context result, and no rank entered a barrier
+    between construction and close()."""
+    import socket
+    w, h, n_planes, world = 1920, 1080, 8, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "helpers" / "peer_stream_rank.py"), str(w), str(h), str(n_planes),
+                                       str(tmp_path / f"rank{r}.npy")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p_ in procs:
+        try:
+            o, e = p_.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()                                   # exactly the processes this test started
+            raise
+        outs.append((p_.returncode, o, e))
+    assert all(rc == 0 for rc, _, _ in outs), [(rc, o[-300:], e[-1500:]) for rc, o, e in outs]
+    assert all("barriers during the stream: 0" in o for _, o, _ in outs)
+    parts = [np.load(tmp_path / f"rank{r}.npy") for r in range(world)]
+    for g in range(n_planes):
+        got = np.concatenate([p_[g] for p_ in parts], axis=0)
+        assert np.array_equal(got, gpu_ctx.forward_y(synth_luma(w, h, frame=g))), g
+
+
+@pytest.mark.parametrize("n_ctx,w,h,n_planes", [(3, 1920, 1080, 7), (2, 700, 210, 5), (3, 1280, 96, 6), (1, 640, 360, 3)])
+def test_striped_frames_pipeline_equals_single_context(gpu_ctx, ctx_pool, n_ctx, w, h, n_planes):
+    """srcnn_forward_y_striped_frames: a STREAM of different planes, each row-striped over the contexts, uploads / kernels /
+    downloads of neighbouring planes overlapped and ordered across contexts by events only (the one-shot
+    srcnn_forward_y_striped synchronises every context twice per plane).  Every plane equals the single-context result --
+    thin stripes (24 rows), one context, an odd number of planes, the REFBYTES mode and a repeated call included."""
+    planes = synth_batch(w, h, n_planes, first_frame=21)
+    want = np.stack([gpu_ctx.forward_y(p) for p in planes])
+    got = S.forward_y_striped_frames(ctx_pool[:n_ctx], planes)
+    assert np.array_equal(got, want)
+    assert np.array_equal(S.forward_y_striped_frames(ctx_pool[:n_ctx], planes[::-1].copy()), want[::-1])      # buffers reused
+    if n_ctx == 2:
+        for c in ctx_pool[:n_ctx]:
+            c.set_mode(S.MODE_REFBYTES)
+        try:
+            ref = np.stack([oracle.forward_y(p, S.load_weights())[0] for p in planes])
+            assert np.array_equal(S.forward_y_striped_frames(ctx_pool[:n_ctx], planes), ref)
+        finally:
+            for c in ctx_pool[:n_ctx]:
+                c.set_mode(S.MODE_MFMA)

@@ -465,6 +465,15 @@ def test_in_place_calls_are_rejected(gpu_ctx):
         gpu_ctx.forward_y_dev(buf.data_ptr(), w, h * w, buf.data_ptr() + 10 * w, w, h * w, w, h, 1)
     gpu_ctx.forward_y_dev(buf.data_ptr(), w, h * w, buf.data_ptr() + h * w, w, h * w, w, h, 1)     # adjacent halves: fine
     gpu_ctx.synchronize()
+    # the stripe entry point with separate halo buffers: the output rows may overlap neither the stripe nor a halo buffer
+    own, halo, out = buf[:32], torch.zeros((6, w), dtype=torch.uint8, device="cuda"), torch.zeros((32, w), dtype=torch.uint8, device="cuda")
+    args = lambda dst, top, bot: (own.data_ptr(), w, 16, 32, top, bot, w, dst, w, 16, w, h, 16, 48)
+    for dst, top, bot in ((own.data_ptr(), halo.data_ptr(), halo.data_ptr()), (out.data_ptr(), out.data_ptr(), halo.data_ptr()),
+                          (out.data_ptr(), halo.data_ptr(), out.data_ptr() + 20 * w)):
+        with pytest.raises(S.SrcnnError):
+            gpu_ctx.forward_y_rows_halo_dev(*args(dst, top, bot))
+    gpu_ctx.forward_y_rows_halo_dev(*args(out.data_ptr(), halo.data_ptr(), halo.data_ptr()))
+    gpu_ctx.synchronize()
 
 
 def test_error_paths(gpu_ctx):

@@ -65,7 +65,7 @@ def test_other_vertical_pass_variants_are_attributed_to_the_resize(butterfly, we
 
 def test_gpu_order_model_also_lands_on_the_reference_output(butterfly, weights_blob):
     """The model of the HIP kernels' arithmetic (fused multiply-adds, tap-partial layer 3) differs from the reference
-    arithmetic on a handful of pixels that sit on a truncation boundary (DESIGN.md section 5)."""
+    arithmetic on a handful of pixels that sit on a truncation boundary (DESIGN.md section 6)."""
     src, ref = butterfly
     out = oracle.process_bgr(src, 1.5, weights_blob, y_path=oracle.gpuorder_forward_y)
     d = np.abs(out.astype(int) - ref.astype(int))

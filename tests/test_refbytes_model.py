@@ -1,4 +1,4 @@
-"""CPU check of the PRINCIPLE behind SRCNN_MODE_REFBYTES (csrc/srcnn_exact.hip, DESIGN.md section 4.4), with the two CPU
+"""CPU check of the PRINCIPLE behind SRCNN_MODE_REFBYTES (csrc/srcnn_exact.hip, DESIGN.md section 4.3), with the two CPU
 restatements only -- oracle/srcnn_gpuorder.c is bitwise the GPU's float32 MFMA path, oracle/srcnn_oracle.c the reference
 arithmetic: a byte of the MFMA path can differ from the reference's only where its pre-truncation value v lies within delta of
 an integer (and 0.5 < v < 255.5), so replacing exactly those pixels by the reference's gives the reference's plane.  The GPU
