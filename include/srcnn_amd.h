@@ -179,6 +179,10 @@ int srcnn_dev_upload(srcnn_ctx *ctx, void *d_dst, const void *src, size_t bytes)
  * -- on the same or another GPU of the node -- turns it into a device address of its own with srcnn_ipc_open (accesses from
  * another GPU travel over xGMI) and gives it back with srcnn_ipc_close before the owner frees the memory.  The ranks of a
  * row-striped plane use this to read each other's 6 edge rows where they lie (srcnn_forward_y_rows_halo_dev). */
+/* ORDERING: a launch that reads through a mapping sees what the owner's device has COMPLETED; nothing orders it behind work
+ * still queued in the owning process.  The ranks agree out of band that a plane is in place before a neighbour steps on it and
+ * that the steps on it are done before it is overwritten (srcnn_cpp_amd/sharding.py: PeerStripeStep's "uploaded" / "done"
+ * messages). */
 int srcnn_ipc_export(srcnn_ctx *ctx, void *d_ptr, unsigned char handle[64]);
 int srcnn_ipc_open(srcnn_ctx *ctx, const unsigned char handle[64], void **d_ptr);
 int srcnn_ipc_close(srcnn_ctx *ctx, void *d_ptr);
@@ -251,9 +255,15 @@ int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx,
                                    int width, int height, int n_planes);
 
 /* Same on device memory: d_stripes[k] / d_out[k] are DEVICE pointers on
- * ctxs[k]'s GPU to that context's rows of the input / output plane.  The inputs
- * must be complete when the call is made; the work is asynchronous on each
- * context's stream (srcnn_synchronize every context to wait). */
+ * ctxs[k]'s GPU to that context's rows of the input / output plane.  The work is
+ * asynchronous on each context's stream (srcnn_synchronize every context to wait).
+ * ORDERING IS THE CALLER'S: context k's launch reads the edge rows of d_stripes[k-1]
+ * and d_stripes[k+1] where they lie -- on another device, over the link -- and nothing
+ * in this call orders it behind whatever PRODUCES those rows on the neighbours' streams.
+ * All n_ctx stripes must be complete (host-synchronised, or ordered by the caller's own
+ * cross-device events) when the call is made, and must stay unchanged until every
+ * context of the set has finished the step.  srcnn_forward_y_striped and
+ * srcnn_forward_y_striped_frames provide that ordering themselves. */
 int srcnn_forward_y_striped_dev(srcnn_ctx *const *ctxs, int n_ctx,
                                 const uint8_t *const *d_stripes, size_t stripe_stride,
                                 uint8_t *const *d_out, size_t out_stride, int width, int height);

@@ -87,7 +87,7 @@ typedef const __attribute__((address_space(4))) float *cfloat_p;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cfloat_p as_constant(const float *p) { return (cfloat_p)p; }
 
-// The fix-up kernel's layers 1-2 (exact_layer1_half / exact_layer2_half below) read the luma window from LDS --
+// The fix-up kernel's layers 1-2 (exact_layer1_half / exact_layer2_quarter below) read the luma window from LDS --
 // win[i * PITCH + j] is the (already border-replicated) value under tap (i, j) -- and run TAP-OUTER: the layer-1 sums of a
 // position advance together, one luma value against the weights of its tap (W1 transposed [81][64] at wraw + 10177) -- per
 // channel the same rounded products added in the same order as the reference's loop (src/srcnn.cpp:283-305), but independent
@@ -102,10 +102,9 @@ typedef f32x16 f32x16_a4 __attribute__((aligned(4)));
 typedef const __attribute__((address_space(4))) f32x16_a4 *cvec16_p;
 
 // The same arithmetic for HALF a feature position: the 32 layer-1 channels [32 hh, 32 hh + 32) of the lane's position (hh is
-// wave-uniform: the weights stay scalar operands), then the lane's share of every layer-2 chain -- input channels
-// [32 hh, 32 hh + 32) folded, in ascending order, into the 32 running sums r[], which for hh = 1 arrive holding the hh = 0
-// lane's result.  Two lanes per position halve the time one work item of fix_apply_kernel takes; every chain keeps the
-// reference's order (src/srcnn.cpp:288-317).
+// wave-uniform: the weights stay scalar operands); layer 2 then gives the lane 16 of the 32 output chains (exact_layer2_quarter).
+// Two lanes per position halve the time one work item of fix_apply_kernel takes; every chain keeps the reference's order
+// (src/srcnn.cpp:288-317).
 // Scalar loads return out of order, so the only wait for one is lgkmcnt(0) -- which also waits for every load issued since.
 // A tap's weights are therefore fetched ONE TAP AHEAD and the wait is pinned (an empty asm that reads the registers) in front of
 // the next fetch: [wait for tap t] [fetch tap t + 1] [32 packed operations of tap t] -- the fetch has the whole tap to arrive.
@@ -167,31 +166,36 @@ __device__ __forceinline__ void exact_layer1_half(const float *win, const float 
         acc[c] = a;
     }
 }
-// layer 2, this lane's 32 input channels: the next channel's 32 weights are fetched while the current one's products run
-__device__ __forceinline__ void exact_layer2_half(const f32x2 (&acc)[16], const float *wraw, int hh, f32x2 (&r)[16])
+// Layer 2: a lane folds 32 consecutive input channels [in0, in0 + 32) -- a(i) delivers channel in0 + i: its own layer-1
+// activations from registers, or its partner lane's through LDS -- into the 16 output chains [16 hh, 16 hh + 16) it owns.  Both
+// lanes of a position work at the same time: the chains of the hh = 0 lane take inputs 0-31 from its registers, then 32-63 from
+// the partner; those of the hh = 1 lane 0-31 from the partner, then its own.  Every chain still sees its 64 inputs in ascending
+// order (src/srcnn.cpp:312-315).  One 16-float scalar load per input channel, fetched one ahead, two output channels per packed
+// instruction with the weights as a scalar-register pair.  (Round 4 split layer 2 by INPUT channel: each lane carried all 32
+// chains through its 32 inputs, the hh = 1 lane continuing where the hh = 0 lane stopped -- the two halves ran one after the
+// other, 2,048 packed instructions on an item's critical path instead of 1,024, and half the workgroup's waves idle meanwhile:
+// fix_apply 166 -> 162 us on a 3840x2160 plane, profiles/r05/fix_apply_ab.txt step 5.)
+template <class In>
+__device__ __forceinline__ void exact_layer2_quarter(In a, const float *wraw, int hh, int in0, f32x2 (&r)[8])
 {
-    const cvec16_p w2t = (cvec16_p)(as_constant(wraw) + 8129 + 32 * hh * 32);      // input channel i at w2t[2 i], [2 i + 1]
-    f32x16 w0c = w2t[0], w1c = w2t[1];
+    const cvec16_p w2t = (cvec16_p)(as_constant(wraw) + 8129 + in0 * 32 + 16 * hh);      // input i at w2t[2 i] (a row of W2T is 32 floats)
+    f32x16 wc = w2t[0];
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        asm volatile("" ::"s"(w0c), "s"(w1c));
-        // (the fetch behind the last channel of hh = 1 reads the first tap of the W1T table that follows: in bounds)
-        const f32x16 w0n = w2t[2 * (i + 1)], w1n = w2t[2 * (i + 1) + 1];
+        asm volatile("" ::"s"(wc));
+        // (the fetch behind the last channel reads into the W1T table that follows: in bounds)
+        const f32x16 wn = w2t[2 * (i + 1)];
         __builtin_amdgcn_sched_barrier(0);
-        const float ai = (i & 1) ? acc[i >> 1].y : acc[i >> 1].x;
+        const float ai = a(i);
         const f32x2 aa = {ai, ai};
-        // two output channels per packed instruction, the weights as a scalar-register pair (the rounded product and the
-        // rounded add of either half are what the plain instructions give)
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f32x2 wa = {w0c[2 * k], w0c[2 * k + 1]}, wb = {w1c[2 * k], w1c[2 * k + 1]};
-            const f32x2 p0 = wa * aa, p1 = wb * aa;
+            const f32x2 wa = {wc[2 * k], wc[2 * k + 1]};
+            const f32x2 p0 = wa * aa;
             r[k] = r[k] + p0;
-            r[8 + k] = r[8 + k] + p1;
         }
         __builtin_amdgcn_sched_barrier(0);
-        w0c = w0n;
-        w1c = w1n;
+        wc = wn;
     }
 }
 
@@ -454,10 +458,9 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
 //
 // TWO LANES PER FEATURE POSITION.  Lane t works on position q = t & 127 -- tap q % 25 of scattered pixel q / 25, or position
 // (q / 16, q % 16) of a dense sub-window -- with hh = t >> 7 (wave-uniform, so the weights stay scalar operands): it computes the
-// layer-1 channels [32 hh, 32 hh + 32) of the position (exact_layer1_half) and folds them into the 32 layer-2 chains
-// (exact_layer2_half).  A layer-2 sum is ONE chain over the 64 input channels in ascending order (src/srcnn.cpp:312-315), so the
-// hh = 1 lane continues where the hh = 0 lane of its position stopped: the 32 running sums cross through LDS, one barrier
-// between the two halves of layer 2 (other workgroups of the CU fill the wait).  Round 3 ran one lane per position, 250 per
+// layer-1 channels [32 hh, 32 hh + 32) of the position (exact_layer1_half) and 16 of its 32 layer-2 output chains
+// (exact_layer2_quarter): the two lanes swap their 32 activations through LDS, half at a time, so that each chain sees its 64
+// inputs in ascending order (src/srcnn.cpp:312-315).  Round 3 ran one lane per position, 250 per
 // item: an item took ~62 us, 3,390 of them over 1,024 resident workgroups = 3.3 rounds, the last one two thirds empty, and on a
 // 1920x1080 plane the whole fix-up was ONE item's latency.  Now an item is half as long (5 scattered pixels), the last round
 // costs half as much, and the registers a lane no longer needs (32 channel sums instead of 64) buy a fifth workgroup per CU.
@@ -497,25 +500,34 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
     auto layers12 = [&](const float *win, auto pitch) {
         f32x2 acc[16];
         exact_layer1_half<decltype(pitch)::value>(win, p.wraw, hh, acc);
-        f32x2 r[16];
+        auto own = [&](int i) { return (i & 1) ? acc[i >> 1].y : acc[i >> 1].x; };
+        auto theirs = [&](int i) { return Fs[q][i]; };
+        f32x2 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = f32x2{0.f, 0.f};
+        // input channels 0-31: the hh = 0 lane's activations
         if (hh == 0) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) r[k] = f32x2{0.f, 0.f};
-            exact_layer2_half(acc, p.wraw, 0, r);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = r[k].x; Fs[q][2 * k + 1] = r[k].y; }
+            for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = acc[k].x; Fs[q][2 * k + 1] = acc[k].y; }
         }
-        __syncthreads();                     // (also: the previous item's layer 3 finished with Fs before the first barrier of this one)
+        __syncthreads();
+        if (hh == 0) exact_layer2_quarter(own, p.wraw, 0, 0, r);
+        else exact_layer2_quarter(theirs, p.wraw, 1, 0, r);
+        __syncthreads();                     // the hh = 1 lanes are done reading
+        // input channels 32-63: the hh = 1 lane's
         if (hh == 1) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) r[k] = f32x2{Fs[q][2 * k], Fs[q][2 * k + 1]};
-            exact_layer2_half(acc, p.wraw, 1, r);
+            for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = acc[k].x; Fs[q][2 * k + 1] = acc[k].y; }
+        }
+        __syncthreads();
+        if (hh == 1) exact_layer2_quarter(own, p.wraw, 1, 32, r);
+        else exact_layer2_quarter(theirs, p.wraw, 0, 32, r);
+        __syncthreads();                     // the hh = 0 lanes are done reading
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float v0 = r[k].x + b2[2 * k], v1 = r[k].y + b2[2 * k + 1];
-                Fs[q][2 * k] = (v0 < 0) ? 0.f : v0;
-                Fs[q][2 * k + 1] = (v1 < 0) ? 0.f : v1;
-            }
+        for (int k = 0; k < 8; ++k) {
+            const float v0 = r[k].x + b2[16 * hh + 2 * k], v1 = r[k].y + b2[16 * hh + 2 * k + 1];
+            Fs[q][16 * hh + 2 * k] = (v0 < 0) ? 0.f : v0;
+            Fs[q][16 * hh + 2 * k + 1] = (v1 < 0) ? 0.f : v1;
         }
         __syncthreads();
     };
