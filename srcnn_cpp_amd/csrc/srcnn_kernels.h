@@ -202,7 +202,7 @@ hipError_t launch_strip(int mode, const StripParams &p, int n_frames, hipStream_
 struct FoldParams {
     StripParams prev;
     const int *seams;               // prev's seam table {strip, row} per seam
-    const unsigned char *winmap;    // prev's rows inside a seam window, per strip
+    const unsigned char *winmap;    // prev's rows inside a seam window, per strip; null: prev has row seams only (cblocks = 0)
     int n_seams, cblocks, first_block;
 };
 hipError_t launch_strip_fold(const StripParams &p, const FoldParams &f, hipStream_t stream, size_t lds_pad = 0);

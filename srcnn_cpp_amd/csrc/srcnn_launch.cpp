@@ -34,7 +34,8 @@ int flush_seams(srcnn_ctx *c)
     if (!c || !c->pending.valid) return SRCNN_OK;
     c->pending.valid = false;
     const FoldParams &f = c->pending.f;
-    HIP_TRY(c, launch_seams_merged(f.prev, f.n_seams, f.seams, f.winmap, 1, c->pending.stream));
+    if (f.winmap) HIP_TRY(c, launch_seams_merged(f.prev, f.n_seams, f.seams, f.winmap, 1, c->pending.stream));
+    else HIP_TRY(c, launch_seams(f.prev, f.n_seams, f.seams, c->pending.stream));
     return SRCNN_OK;
 }
 
@@ -167,7 +168,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
                 // Seam deferral: this launch's seam blocks will ride behind the NEXT launch's work items, which writes its own
                 // exports meanwhile -- the two scratch sets of the stream are used in turn.
                 defer = may_defer && c->defer_seams && c->defer_block == 0 && !c->safe_hazards && fused32 && n_frames == 1 && !p.pre && !(p.tune & 16) &&
-                        table->separated && table->n_seams > 0 && col_seams &&
+                        table->n_seams > 0 && (col_seams ? table->separated : true) &&
                         !(c->mode == SRCNN_MODE_REFBYTES || c->mode == SRCNN_MODE_REFBYTES16);
                 if (defer) sc->flip ^= 1;
                 DevBuf &rbuf = defer && sc->flip ? sc->buf2 : sc->buf, &cbuf = defer && sc->flip ? sc->cbuf2 : sc->cbuf;
@@ -281,9 +282,9 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         FoldParams &f = c->pending.f;
         f.prev = p;
         f.seams = static_cast<const int *>(table->dev_seams.p);
-        f.winmap = static_cast<const unsigned char *>(table->dev_winmap.p);
+        f.winmap = p.cseam ? static_cast<const unsigned char *>(table->dev_winmap.p) : nullptr;
         f.n_seams = table->n_seams;
-        f.cblocks = (int)(((long)(p.strips_total - 1) * (p.row_end - p.row_begin) + 255) / 256);
+        f.cblocks = p.cseam ? (int)(((long)(p.strips_total - 1) * (p.row_end - p.row_begin) + 255) / 256) : 0;
         f.first_block = 0;
         c->pending.stream = c->stream;
         c->pending.valid = true;

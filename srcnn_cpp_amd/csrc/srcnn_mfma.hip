@@ -1005,8 +1005,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void srcnn_strip_fold_kernel(const Str
 {
     if ((int)blockIdx.x >= f.first_block) {         // (uniform per block)
         const int q = (int)blockIdx.x - f.first_block;
-        if (q < f.n_seams) seam_block<false, true, false>(f.prev, f.seams, q);
-        else cseam_block<false, false>(f.prev, (long)(q - f.n_seams), 0, f.winmap);
+        if (q >= f.n_seams) cseam_block<false, false>(f.prev, (long)(q - f.n_seams), 0, f.winmap);
+        else if (f.winmap) seam_block<false, true, false>(f.prev, f.seams, q);      // row seams + the column-seam pixels of their rows
+        else seam_block<false, false, false>(f.prev, f.seams, q);                   // a plan without column seams (narrow planes)
         return;
     }
     fast::strip_body<MODE_FUSED, false, 0, false, HALO3>(p);

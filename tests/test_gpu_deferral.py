@@ -203,3 +203,23 @@ def test_entry_points_that_read_their_own_launches_never_defer(ctx, weights_blob
     assert np.array_equal(S.forward_y_striped([ctx] + others, frames[2]), plain.forward_y(frames[2]))
     for c in others + [plain]:
         c.close()
+
+
+@pytest.mark.parametrize("w,h", [(576, 576), (960, 540), (1280, 720), (700, 300), (3840, 200)])
+def test_small_and_narrow_planes_defer_too(ctx, weights_blob, w, h):
+    """Plans without column seams (576 and 960 columns keep their two halo columns: row seams only), plans whose seam windows
+    are not kept apart, planes too small for work items at all: whatever the plan, a stream of five planes with deferral on
+    equals the planes one by one -- deferred where the plan allows it, launch by launch where not."""
+    import torch
+    frames = synth_batch(w, h, 5, first_frame=40)
+    d_in = torch.from_numpy(frames).cuda()
+    got = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    ctx.set_seam_deferral(True)
+    for k in range(5):
+        ctx.forward_y_dev(d_in[k].data_ptr(), w, 0, got[k].data_ptr(), w, 0, w, h, 1)
+    ctx.flush()
+    ctx.synchronize()
+    got = got.cpu().numpy()
+    for k in range(5):
+        assert np.array_equal(got[k], oracle.gpuorder_forward_y(frames[k], weights_blob)[0]), k

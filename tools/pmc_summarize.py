@@ -32,11 +32,24 @@ def writes_flags(name):
 traffic_rec = {}
 for mode, knames in KERNEL.items():
     kname = knames[0]
+    # Round 5: with seam deferral (the bench default) the step IS srcnn_strip_fold_kernel -- the strip kernel's row body on the
+    # work items plus the previous step's seam blocks behind them; the plain strip kernel and the seam launch then run once per
+    # process (first and last step).  The fold kernel's counters are the step's.
+    files = glob.glob(os.path.join(out, f"pmc_{mode}_*", "**", "*counter_collection.csv"), recursive=True)
+    folded = False
+    if mode == "mfma":
+        for f in files:
+            with open(f, newline="") as fh:
+                if any("srcnn_strip_fold_kernel" in row["Kernel_Name"] for row in csv.DictReader(fh)):
+                    folded = True
+                    break
+    if folded:
+        kname, knames = "srcnn_strip_fold_kernel", ["srcnn_strip_fold_kernel"]
     sums, cnt = defaultdict(float), defaultdict(int)
     extra = defaultdict(lambda: defaultdict(float))
     extra_cnt = defaultdict(lambda: defaultdict(int))
     grid = None
-    for f in glob.glob(os.path.join(out, f"pmc_{mode}_*", "**", "*counter_collection.csv"), recursive=True):
+    for f in files:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
                 if writes_flags(row["Kernel_Name"]):
@@ -87,7 +100,8 @@ for mode, knames in KERNEL.items():
     traffic_rec[("fused" if mode == "mfma" else mode) + "_3840x2160x1"] = d.get("hbm_bytes_step")
     if "mfma_busy_frac_of_simd_cycles" in d:
         traffic_rec[("fused" if mode == "mfma" else mode) + "_3840x2160x1_mfma_busy_frac"] = round(d["mfma_busy_frac_of_simd_cycles"], 4)
-    summary = {"kernel": f"{kname} 3840x2160x1, {grid} workgroups", "rocprof_kernel_trace_avg_ns": avg_ns,
+    summary = {"kernel": f"{kname} 3840x2160x1, {grid} workgroups" + (" (512 work items + the previous step's seam blocks)" if folded else ""),
+               "rocprof_kernel_trace_avg_ns": avg_ns,
                "counters_mean_per_dispatch": mean, "derived": d}
     with open(os.path.join(out, f"{mode}_4k_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
@@ -141,7 +155,7 @@ if unf:
         json.dump(rec, fh, indent=1)
     print("unfused", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in rec.items()}))
 
-traffic_rec["_note"] = ("per step (one 3840x2160 plane): HBM bytes of the strip kernel plus, in the float32 mode, the two seam kernels; "
+traffic_rec["_note"] = ("per step (one 3840x2160 plane): HBM bytes of the strip kernel plus, in the float32 mode, the seam blocks (with seam deferral they run inside srcnn_strip_fold_kernel, whose counters are the step's); "
                         "FETCH_SIZE x2 (every read width is reported at half its size: profiles/r02/pmc_calibration.txt) + WRITE_SIZE, KB -> bytes; "
                         "separate --pmc passes (tools/profile_round.sh); *_mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the strip kernel")
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
