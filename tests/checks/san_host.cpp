@@ -19,17 +19,16 @@ hipError_t launch_seams(const StripParams &, int, const int *, hipStream_t) { re
 hipError_t launch_cseams(const StripParams &, int, hipStream_t) { return never(); }
 hipError_t launch_seams_merged(const StripParams &, int, const int *, const unsigned char *, int, hipStream_t) { return never(); }
 hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
+hipError_t launch_strip_fold(const StripParams &, const FoldParams &, hipStream_t, size_t) { return never(); }
 hipError_t launch_strip_safe(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
-long interlock_probe_mismatches(int) { return 0; }
-hipError_t launch_fixup(const FixParams &, int, hipStream_t) { return never(); }
+long interlock_probe_mismatches(int, hipStream_t) { return 0; }
+hipError_t launch_fixup(const FixParams &, int, bool, hipStream_t) { return never(); }
 size_t fixup_list_entries(int, int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv11_exact(const float *, long, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_conv99x11_exact(const uint8_t *, long, long, float *, long, long, long, int, int, int, const float *, hipStream_t) { return never(); }
 hipError_t launch_conv55_exact(const float *, long, long, long, uint8_t *, float *, long, long, int, int, int, const float *, float, hipStream_t) { return never(); }
-hipError_t launch_conv99x11_exact_rows(const uint8_t *, long, int, float *, long, long, int, int, int, int, int, const float *, hipStream_t) { return never(); }
-hipError_t launch_conv55_exact_rows(const float *, long, long, int, int, uint8_t *, long, int, int, int, int, int, const float *, float, hipStream_t) { return never(); }
 hipError_t launch_copy_rows(uint8_t *, long, const uint8_t *, long, int, int, hipStream_t) { return never(); }
 hipError_t launch_bgr2ycrcb(const uint8_t *, long, int, int, uint8_t *, long, long, hipStream_t) { return never(); }
 hipError_t launch_ycrcb2bgr(const uint8_t *, long, const uint8_t *, long, long, int, int, uint8_t *, long, hipStream_t) { return never(); }
