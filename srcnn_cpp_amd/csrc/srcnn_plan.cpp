@@ -78,6 +78,8 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
 {
     const ItemPlan none;
     constexpr int kMinRows = 10;
+    constexpr int kSepMinRows = 24;           // items at least this tall: worth trying to keep the seam windows of neighbouring strips apart
+    constexpr double kLaunchSaved = 2.0;      // us a separated plan may cost in balance: what one seam launch instead of two saves, conservative
     const int hs = row_end - row_begin;
     const int slots = 2 * n_cu;
     if (n_cu <= 0 || n_strips <= 0 || n_strips > n_cu || hs <= 0 || slots / n_strips < 2 || hs / (slots / n_strips + 1) < kMinRows + 2)
@@ -239,7 +241,9 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
     const std::vector<Item> start = items;
     static const char *env_sep = SRCNN_DEBUG_ENV("SRCNN_DEBUG_SEPARATE");     // experiment knob: 0 = never keep the seam windows apart
     // (worth trying only with neighbours to keep apart from and items tall enough to give up a few rows)
-    bool separated = !(env_sep && std::atoi(env_sep) == 0) && n_strips >= 2 && hs / (kbase + 1) >= 24;
+    static const char *env_sep_rows = SRCNN_DEBUG_ENV("SRCNN_DEBUG_SEP_MINROWS"), *env_sep_saved = SRCNN_DEBUG_ENV("SRCNN_DEBUG_SEP_SAVED");   // experiment knobs
+    const int sep_min_rows = env_sep_rows ? std::atoi(env_sep_rows) : kSepMinRows;
+    bool separated = !(env_sep && std::atoi(env_sep) == 0) && n_strips >= 2 && hs / (kbase + 1) >= sep_min_rows;
     constexpr int kSlack = 4;        // preferred extra distance: the search needs room to move boundaries
     for (int s_ = 1; s_ < n_strips && separated; ++s_) {
         const std::vector<int> left = bounds(s_ - 1);
@@ -289,8 +293,8 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
     items = start;
     for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
     search(false);
-    constexpr double kLaunchSaved = 2.0;      // us, conservative
-    if (separated && apart_t <= slowest() + kLaunchSaved) {
+    const double launch_saved = env_sep_saved ? std::atof(env_sep_saved) : kLaunchSaved;
+    if (separated && apart_t <= slowest() + launch_saved) {
         items = apart_items;
         for (int c = 0; c < n_cu; ++c) fin[(size_t)c] = finish(c);
     } else {

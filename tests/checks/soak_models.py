@@ -7,12 +7,15 @@ import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch  # noqa: F401
+import os
 import oracle, srcnn_cpp_amd as S
+os.makedirs("gpurun_out", exist_ok=True)
 from srcnn_cpp_amd.synth import synth_luma
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 n, n16, worst, worst16, reruns, t0 = 0, 0, 0.0, 0.0, 0, time.time()
+oracle_flakes = []
 while time.time() - t0 < budget:
     s1, s2, s3 = rng.uniform(0.03, 0.25), rng.uniform(0.03, 0.4), rng.uniform(0.005, 0.08)
     w1 = (rng.standard_normal(5184) * s1).astype(np.float32)
@@ -40,7 +43,23 @@ while time.time() - t0 < budget:
                 assert mode == S.MODE_REFBYTES16 and e.code == S.ERR_STATE, e      # the model exceeds the f16 ranges: refused
                 continue
             st = ctx.fixup_stats()
-            assert np.array_equal(out, r_out), (mode, n, w, h, kind, s1, s2, s3, int((out != r_out).sum()), st)
+            if not np.array_equal(out, r_out):
+                # Before blaming the kernels, ask the CHECKER again.  Round 5 met, twice in ~11,000 planes on the GPU boxes, an
+                # oracle.forward_y whose result was wrong in one band of rows: a second run of the same call, the oracle recomputed
+                # in the build container and the GPU's bytes all agreed with each other (profiles/r05/soak_long.txt).  Such a plane
+                # is counted and reported, and judged by the second run; a result that differs from BOTH runs is the product's.
+                r2 = oracle.forward_y(y, blob)[0]
+                if np.array_equal(out, r2):
+                    ys = np.nonzero((r_out != r2).any(axis=1))[0]
+                    oracle_flakes.append((n, w, h, int((r_out != r2).sum()), int(ys.min()), int(ys.max())))
+                    r_out = r2
+                else:
+                    ys, xs = np.nonzero(out != r2)
+                    again = ctx.forward_y(y)
+                    np.savez("gpurun_out/soak_models_failure.npz", blob=blob, y=y, out=out, r_out=r_out, r2=r2, again=again)
+                    raise AssertionError((mode, n, w, h, int(kind), s1, s2, s3, len(ys), st, "rows", int(ys.min()), int(ys.max()), "cols", int(xs.min()),
+                                          int(xs.max()), "repeat call differs from the oracle in", int((again != r2).sum()),
+                                          "the two oracle runs differ in", int((r2 != r_out).sum())))
             ratio = st["max_dev"] / st["delta"] if st["delta"] > 0 else 0.0
             # above delta / 2 the device-side net must have redone the launch (the bytes above are already checked)
             assert ratio < 0.5 or st["exact_reruns"] >= 1, (mode, n, st, s1, s2, s3)
@@ -52,4 +71,5 @@ while time.time() - t0 < budget:
     n += 1
 print(f"soak_models ok: {n} random models x planes in {time.time() - t0:.0f} s ({n16} of them also in REFBYTES16); every plane bytewise equal "
       f"to the reference arithmetic; largest monitored deviation / threshold = {worst:.3f} (REFBYTES16: {worst16:.3f}); "
-      f"{reruns} launches were over delta / 2 and redone by the device-side net")
+      f"{reruns} launches were over delta / 2 and redone by the device-side net"
+      + (f"; ORACLE ANOMALIES (first run of oracle.forward_y disagreed with a second run AND with the GPU; (n, w, h, bytes, rows)): {oracle_flakes}" if oracle_flakes else ""))

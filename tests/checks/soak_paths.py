@@ -12,6 +12,8 @@ kernels' arithmetic (oracle.gpuorder_*):
     another row stride -- in the MFMA mode (against the model) and in SRCNN_MODE_REFBYTES (against the reference arithmetic),
     in strict mode every now and then with the threshold cut below the noise (the exact re-run path)
   * Convolution99x11 -> Convolution55 through the device entry points (aligned 128-column strips in the second)
+  * seam deferral (round 5): a random stream of whole-plane and row-range launches on two planes of different sizes, outputs
+    shared or fresh, every one complete and bitwise right after flush()
 """
 import sys, time
 from pathlib import Path
@@ -97,6 +99,41 @@ while time.time() - t0 < budget:
             if strict:
                 ctx.set_fixup_margin(4.0)
         ctx.set_mode(S.MODE_MFMA)
+    # seam deferral: a stream of launches on this plane and a second one of another size -- whole planes and row ranges, into
+    # one shared output buffer per plane or a fresh one, interleaved -- every output complete after flush()
+    if w * h <= 4_500_000:
+        note("deferral stream", w, h)
+        w2, h2 = int(rng.choice([576, 960, 1280, 1920, w])), int(rng.choice([360, 540, 720, h]))
+        y2 = synth_luma(w2, h2, frame=int(rng.integers(0, 99)))
+        m2 = oracle.gpuorder_forward_y(y2, blob)[0]
+        d1, d2 = torch.from_numpy(y).cuda(), torch.from_numpy(y2).cuda()
+        o1, o2 = torch.zeros_like(d1), torch.zeros_like(d2)
+        fresh = []
+        torch.cuda.synchronize()
+        ctx.set_seam_deferral(True)
+        for _ in range(int(rng.integers(3, 8))):
+            which = rng.integers(0, 4)
+            if which == 0:
+                ctx.forward_y_dev(d1.data_ptr(), w, 0, o1.data_ptr(), w, 0, w, h, 1)
+            elif which == 1:
+                ctx.forward_y_dev(d2.data_ptr(), w2, 0, o2.data_ptr(), w2, 0, w2, h2, 1)
+            elif which == 2 and h >= 40:
+                r0 = int(rng.integers(0, h - 20)); r1 = int(rng.integers(r0 + 7, h + 1))
+                s0, s1 = max(0, r0 - 6), min(h, r1 + 6)
+                ctx.forward_y_rows_dev(d1[s0:s1].data_ptr(), w, s0, o1.data_ptr(), w, 0, w, h, r0, r1)      # rows of plane 1 over its own output
+            else:
+                t = torch.zeros_like(d2)
+                fresh.append(t)
+                ctx.forward_y_dev(d2.data_ptr(), w2, 0, t.data_ptr(), w2, 0, w2, h2, 1)
+        ctx.forward_y_dev(d1.data_ptr(), w, 0, o1.data_ptr(), w, 0, w, h, 1)
+        ctx.forward_y_dev(d2.data_ptr(), w2, 0, o2.data_ptr(), w2, 0, w2, h2, 1)
+        ctx.flush()
+        ctx.synchronize()
+        ctx.set_seam_deferral(False)
+        assert np.array_equal(o1.cpu().numpy(), m_out), ("deferral stream, plane 1", w, h, w2, h2)
+        assert np.array_equal(o2.cpu().numpy(), m2), ("deferral stream, plane 2", w, h, w2, h2)
+        for t in fresh:
+            assert np.array_equal(t.cpu().numpy(), m2), ("deferral stream, fresh output", w, h, w2, h2)
     # the two reference functions on device memory
     if w * h <= 4_500_000:
         d_y = torch.from_numpy(y).cuda()
