@@ -78,6 +78,13 @@ def lib() -> C.CDLL:
         _lib.srcnn_adv_point.argtypes = [_u8p, _f32p, _f32p, _f32p]
         _lib.srcnn_adv_search.argtypes = [_f32p, _u8p, i, i, i, C.c_uint64, _u8p, _f32p, _f32p]
         _lib.srcnn_adv_search.restype = C.c_long
+        # One OpenMP thread per logical CPU is the worst choice for a checker that mostly sees small planes: on the 256-thread
+        # hosts of the GPU boxes (shared with other tenants) 256 threads took 0.56 s per 300x260 plane, 64 threads 0.07 s
+        # (tests/checks/oracle_selfcheck.py).  Unless the caller said otherwise (OMP_NUM_THREADS, set_threads()): half the
+        # logical CPUs on large hosts, at most 64.  bench.py's cpu_baseline leg sets its own count (one per physical core).
+        n = os.cpu_count() or 1
+        if "OMP_NUM_THREADS" not in os.environ and n > 32:
+            set_threads(min(n // 2, 64))
     return _lib
 
 

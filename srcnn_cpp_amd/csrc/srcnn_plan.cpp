@@ -78,8 +78,13 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
 {
     const ItemPlan none;
     constexpr int kMinRows = 10;
-    constexpr int kSepMinRows = 24;           // items at least this tall: worth trying to keep the seam windows of neighbouring strips apart
-    constexpr double kLaunchSaved = 2.0;      // us a separated plan may cost in balance: what one seam launch instead of two saves, conservative
+    // Items at least kSepMinRows tall: worth trying to keep the seam windows of neighbouring strips apart; kLaunchSaved = us such a
+    // plan may cost in balance.  One seam launch instead of two saves ~2 us, but in a stream of launches with seam deferral only a
+    // separated plan lets the seam blocks ride behind the next launch (no seam launch at all).  Measured A B B A
+    // (profiles/r05/plan_separation_ab.txt), (12, 8) against round 4's (24, 2): 1280x720 0.743 -> 0.789 of the MFMA peak with
+    // deferral, 0.744 -> 0.753 without; 1366x768 and 1280x1024 the same picture; unchanged plans from 1920x1080 up.
+    constexpr int kSepMinRows = 12;
+    constexpr double kLaunchSaved = 8.0;
     const int hs = row_end - row_begin;
     const int slots = 2 * n_cu;
     if (n_cu <= 0 || n_strips <= 0 || n_strips > n_cu || hs <= 0 || slots / n_strips < 2 || hs / (slots / n_strips + 1) < kMinRows + 2)
@@ -287,7 +292,6 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
         search(true);
     }
     // the unconstrained plan, for comparison: keeping the windows apart must not cost more than the launch it saves
-    // (short items -- 14 rows at 1280x720 -- cannot afford boundaries moved by four rows)
     const std::vector<Item> apart_items = items;
     const double apart_t = separated ? slowest() : 1e30;
     items = start;
