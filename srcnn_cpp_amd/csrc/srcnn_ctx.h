@@ -169,7 +169,7 @@ struct srcnn_ctx {
     // explicit work items of single-round launches (build_items): a small cache of device tables, one per
     // launch geometry, so that a caller alternating between a few plane sizes never waits for an upload
     struct ItemTable {
-        int key[7] = {0, 0, 0, 0, 0, 0, 0};
+        int key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int count = 0;                  // 0: this geometry uses the regular grid
         int n_seams = 0;
         srcnn::host::DevBuf dev, dev_seams;
@@ -321,9 +321,10 @@ struct ItemPlan {
     int count() const { return (int)items.size() / ITEM_INTS; }
     int n_seams() const { return (int)seams.size() / 2; }
 };
-ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2, bool want_seams = false);
+ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2, bool want_seams = false,
+                    int extra_top = 0, int extra_bot = 0);
 int skew_percent();
-int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int height, int wgs_per_cu, bool want_seams,
                 const srcnn_ctx::ItemTable **table);
 int split16_wgs_per_cu(bool split16, int tune);
 int seam_scratch_for_stream(srcnn_ctx *c, srcnn_ctx::SeamScratch **out);

@@ -131,9 +131,9 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         // a plane too small for two items per CU of useful height: one (taller) item per CU still beats the regular grid
         // with its halo rows
         auto items_for = [&](int n_strips_, bool seams_) -> int {
-            int rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, wgs_per_cu, seams_, &table);
+            int rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, p.height, wgs_per_cu, seams_, &table);
             if (!rc2 && table->count == 0 && wgs_per_cu == 2 && seams_)
-                rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, 1, seams_, &table);
+                rc2 = build_items(c, n_strips_, p.row_begin, p.row_end, p.height, 1, seams_, &table);
             return rc2;
         };
         bool col_seams = false;

@@ -74,7 +74,12 @@ double cu_finish_estimate(int fast_rows, int slow_rows, double speed)
     return t / speed;
 }
 
-ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, const double *cu_speed = nullptr)
+// extra_top / extra_bot: feature rows the first / last item of every strip computes beyond its own output rows -- the two rows of
+// layer-3 radius when the launch covers rows [row_begin, row_end) of a taller plane (a rank's stripe: srcnn_forward_y_rows*_dev);
+// at the image's own top and bottom those rows replicate and cost nothing.  They weigh like rows of the item in the balance
+// (a middle rank's 540-row stripe of a 7680-wide plane otherwise finishes one row pair late on the 60 CUs that hold such items).
+ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int extra_top, int extra_bot,
+                             const double *cu_speed = nullptr)
 {
     const ItemPlan none;
     constexpr int kMinRows = 10;
@@ -102,7 +107,7 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
         for (int s = 0; s < n_strips && fast_total < n_cu; ++s)
             if ((pass == 1 || k[(size_t)s] % 2 == 1) && a[(size_t)s] < k[(size_t)s] - 1) { ++a[(size_t)s]; ++fast_total; }
     if (fast_total != n_cu) return none;
-    struct Item { int strip, rows, cu; bool fast; };
+    struct Item { int strip, rows, cu; bool fast; int extra = 0; };      // extra: feature rows computed beyond `rows` (see above)
     std::vector<Item> items;
     const double d = std::min(std::max(skew_pct, 0), 60) / 100.0;
     for (int s = 0; s < n_strips; ++s) {
@@ -114,7 +119,7 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
             const bool fast = (j % 2 == 0) ? (j / 2 < na) : !((j / 2) < nb);
             acc += fast ? (1.0 + d) * u : (1.0 - d) * u;
             const int upto = (j == k[(size_t)s] - 1) ? hs : (int)std::lround(acc);
-            items.push_back({s, upto - used, -1, fast});
+            items.push_back({s, upto - used, -1, fast, (j == 0 ? extra_top : 0) + (j == k[(size_t)s] - 1 ? extra_bot : 0)});
             used = upto;
         }
         // Strips get the same item heights, so their boundaries would line up from strip to strip.  Every second strip
@@ -142,11 +147,12 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
     std::vector<int> fi, si;
     for (int i = 0; i < (int)items.size(); ++i) (items[(size_t)i].fast ? fi : si).push_back(i);
     if ((int)fi.size() != n_cu || (int)si.size() != n_cu) return none;
-    std::stable_sort(fi.begin(), fi.end(), [&](int x, int y) { return items[(size_t)x].rows > items[(size_t)y].rows; });
-    std::stable_sort(si.begin(), si.end(), [&](int x, int y) { return items[(size_t)x].rows < items[(size_t)y].rows; });
+    std::stable_sort(fi.begin(), fi.end(), [&](int x, int y) { return items[(size_t)x].rows + items[(size_t)x].extra > items[(size_t)y].rows + items[(size_t)y].extra; });
+    std::stable_sort(si.begin(), si.end(), [&](int x, int y) { return items[(size_t)x].rows + items[(size_t)x].extra < items[(size_t)y].rows + items[(size_t)y].extra; });
     for (int c = 0; c < n_cu; ++c) items[(size_t)fi[(size_t)c]].cu = items[(size_t)si[(size_t)c]].cu = c;
     auto speed = [&](int c) { return cu_speed && cu_speed[c] > 0.5 && cu_speed[c] < 2.0 ? cu_speed[c] : 1.0; };
-    auto finish = [&](int c) { return cu_finish_estimate(items[(size_t)fi[(size_t)c]].rows, items[(size_t)si[(size_t)c]].rows, speed(c)); };
+    auto work = [&](int i) { return items[(size_t)i].rows + items[(size_t)i].extra; };
+    auto finish = [&](int c) { return cu_finish_estimate(work(fi[(size_t)c]), work(si[(size_t)c]), speed(c)); };
     // local search: take one row from an item of the slowest improvable CU, give it to the item of the same strip
     // whose CU stays fastest; stop when no such move lowers the pair's maximum
     std::vector<std::vector<int>> in_strip((size_t)n_strips);
@@ -338,12 +344,12 @@ ItemPlan plan_items_balanced(int n_cu, int n_strips, int row_begin, int row_end,
 }
 
 ItemPlan plan_items_raw(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu = 2,
-                        bool want_seams = false)
+                        bool want_seams = false, int extra_top = 0, int extra_bot = 0)
 {
     const ItemPlan none;
     static const char *env_plan = SRCNN_DEBUG_ENV("SRCNN_DEBUG_PLAN");      // experiment knob: 1 = the round-1 planner
     if (wgs_per_cu == 2 && want_seams && skew_pct > 0 && !(env_plan && std::atoi(env_plan) == 1)) {
-        const ItemPlan balanced = plan_items_balanced(n_cu, n_strips, row_begin, row_end, skew_pct);
+        const ItemPlan balanced = plan_items_balanced(n_cu, n_strips, row_begin, row_end, skew_pct, extra_top, extra_bot);
         if (balanced.count() > 0) return balanced;
     }
     const int rows = row_end - row_begin;
@@ -426,19 +432,24 @@ int skew_percent()
 // four column-seam pixels either side of its strip on those rows -- the neighbour's values there are complete exports of the
 // strip kernel -- and the row-seam and column-seam kernels no longer depend on each other: one launch instead of two.
 // The balanced planner builds such plans (ItemPlan::separated) where that costs no balance; other plans keep two launches.
-ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu, bool want_seams)
+ItemPlan plan_items(int n_cu, int n_strips, int row_begin, int row_end, int skew_pct, int wgs_per_cu, bool want_seams, int extra_top,
+                    int extra_bot)
 {
-    return plan_items_raw(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams);
+    return plan_items_raw(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams, extra_top, extra_bot);
 }
 
 // Device copy of plan_items() for this geometry, from the context's table cache.  *n_items = 0: use the
 // regular grid.  A table is written once, before its first use, into memory no earlier launch reads
 // (a fresh slot, or an evicted one after its last reader has finished), and never modified afterwards.
-int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_per_cu, bool want_seams,
+int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int height, int wgs_per_cu, bool want_seams,
                 const srcnn_ctx::ItemTable **table)
 {
     *table = nullptr;
-    const int key[7] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu, want_seams ? 1 : 0};
+    static const char *env_edge = SRCNN_DEBUG_ENV("SRCNN_DEBUG_PLAN_EDGES");     // experiment knob: 0 = round 4's plans (edge rows not weighed)
+    const bool edges = !(env_edge && std::atoi(env_edge) == 0);
+    // a launch on rows of a taller plane computes two more feature rows at either open end (plan_items_balanced())
+    const int extra_top = edges && row_begin > 0 ? 2 : 0, extra_bot = edges && row_end < height ? 2 : 0;
+    const int key[8] = {n_strips, row_begin, row_end, skew_percent(), c->n_cu, wgs_per_cu, want_seams ? 1 : 0, extra_top + 4 * extra_bot};
     srcnn_ctx::ItemTable *victim = &c->item_tables[0];
     for (auto &t : c->item_tables) {
         if (t.stamp && std::memcmp(key, t.key, sizeof(key)) == 0) {
@@ -448,7 +459,7 @@ int build_items(srcnn_ctx *c, int n_strips, int row_begin, int row_end, int wgs_
         }
         if (t.stamp < victim->stamp) victim = &t;
     }
-    const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams);
+    const ItemPlan plan = plan_items(c->n_cu, n_strips, row_begin, row_end, key[3], wgs_per_cu, want_seams, extra_top, extra_bot);
     if (victim->stamp) {                                                // evicting: its readers must be done -- and queued
         if (int rc = flush_seams(c)) return rc;                         // (a deferred seam launch may refer to the victim's tables)
         HIP_TRY(c, hipDeviceSynchronize());
@@ -594,7 +605,10 @@ int srcnn_debug_plan_items(int n_cu, int n_strips, int row_begin, int row_end, i
                                       int want_seams, int *items, int max_items, int *seams, int max_seams,
                                       int *n_seams)
 {
-    const ItemPlan plan = plan_items(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams != 0);
+    // wgs_per_cu + 16 * extra_top + 256 * extra_bot: the planner's edge weights ride in the upper bits (old callers: 0)
+    const int extra_top = (wgs_per_cu >> 4) & 15, extra_bot = (wgs_per_cu >> 8) & 15;
+    wgs_per_cu &= 15;
+    const ItemPlan plan = plan_items(n_cu, n_strips, row_begin, row_end, skew_pct, wgs_per_cu, want_seams != 0, extra_top, extra_bot);
     if (plan.count() > max_items || plan.n_seams() > max_seams || !items || !seams || !n_seams) return SRCNN_ERR_INVALID;
     // an empty vector's data() may be null, which memcpy must not be given even for 0 bytes (found by UBSan)
     if (!plan.items.empty()) std::memcpy(items, plan.items.data(), plan.items.size() * sizeof(int));

@@ -141,3 +141,35 @@ def test_worker_pool_of_the_multi_gpu_entry_points():
     assert lib.srcnn_debug_worker_pool(8, 3000) == 0
     assert lib.srcnn_debug_worker_pool(1, 10) == 0
     assert lib.srcnn_debug_worker_pool(0, 1) == -1
+
+
+def _finish_estimate(fast_rows, slow_rows):
+    """cu_finish_estimate() of srcnn_plan.cpp with its default rates."""
+    pf, ps, alone, sf, ss = 6.40, 8.40, 3.76, 3.63, 5.44
+    tf, ts = sf + fast_rows * pf, ss + slow_rows * ps
+    if tf <= ts:
+        return tf + max(0.0, slow_rows - (tf - ss) / ps) * alone
+    return ts + max(0.0, fast_rows - (ts - sf) / pf) * alone
+
+
+@pytest.mark.parametrize("n_strips,r0,r1,top,bot", [(60, 540, 1080, 2, 2), (60, 0, 540, 0, 2), (60, 3780, 4320, 2, 0), (30, 1080, 2160, 2, 2)])
+def test_open_ends_of_a_stripe_weigh_in_the_balance(n_strips, r0, r1, top, bot):
+    """A launch on rows of a taller plane computes two more feature rows at either open end (srcnn_mfma.hip: f_lo, f_hi).  The
+    planner counts them as work of the first / last item of every strip: the plan still tiles the rows exactly, and the CU that
+    finishes last -- with the edge rows counted -- finishes earlier than under the plan that ignores them."""
+    n_cu = 256
+
+    def slowest(it):
+        work = (it[:, 2] - it[:, 1]).copy()
+        work[it[:, 1] == r0] += top
+        work[it[:, 2] == r1] += bot
+        return max(_finish_estimate(work[c], work[n_cu + c]) for c in range(n_cu))
+
+    plain, _ = plan(n_cu, n_strips, r0, r1)
+    edged, se = plan(n_cu, n_strips, r0, r1, per_cu=2 + 16 * top + 256 * bot)
+    assert len(plain) == len(edged) == 2 * n_cu
+    for s in range(n_strips):
+        rows = sorted((int(a), int(b)) for _, a, b, _, _ in edged[edged[:, 0] == s] if b > a)
+        assert rows[0][0] == r0 and rows[-1][1] == r1
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(len(rows) - 1))
+    assert slowest(edged) < slowest(plain) - 3.0            # microseconds of the model: about one row pair

@@ -49,9 +49,12 @@ def main():
     ap.add_argument("--seam-deferral", choices=["on", "off"], default="on",
                     help="on (default, round 5): srcnn_set_seam_deferral(1) -- the seam blocks of step k ride behind the work items of step "
                          "k + 1, the last step's are queued (srcnn_flush) inside the timed window; off: a seam launch per step (round 4)")
+    ap.add_argument("--lib", default=None, help="another build of the library (the tuning build, for the planner's experiment knobs)")
     ap.add_argument("--diag", action="store_true", help="N = 8, rank 1 only: where the cost of the copy + hand-over lies")
     args = ap.parse_args()
     W, H, K = args.width, args.height, args.steps
+    if args.lib:
+        S.use_library(args.lib)
     plane = synth_luma(W, H)
     ctx = S.Context(0)
     ctx.set_weights_blob(S.load_weights())
