@@ -870,6 +870,21 @@ def worker(args):
                                "equals_reference_arithmetic": equal,
                                "checked_against": "sha256 of oracle.forward_y on the same frame (cpu_baseline leg)" if equal is not None
                                                   else "not checked (no whole-plane oracle output in this run)"}
+            # ... and in SRCNN_MODE_REFBYTES16: the same fix-up and the same device-side net behind the split-f16 strip kernel
+            # (opt-in: f16 MFMAs on (hi, lo) operand pairs carry the pass, the float32 reference arithmetic decides every byte
+            # next to a truncation boundary) -- the reference's bytes again, checked against the same sha256.  Never `value`.
+            ctx.set_mode(S.MODE_REFBYTES16)
+            dt_r16 = wall(args.steps)
+            rb16 = d_out.cpu().numpy()
+            equal16 = None
+            if rows == H:
+                equal16 = hashlib.sha256(np.ascontiguousarray(rb16[0]).tobytes()).hexdigest() == ref.get("sha256")
+            out["refbytes16"] = {"ms_per_step": round(dt_r16 * 1e3, 4), "value": round(W * H * F / dt_r16 / 1e6, 2), "unit": "MPix/s",
+                                 "vs_mfma_mode": round(dt_r16 / (elapsed / args.steps), 3), "dtype": "f16 (hi, lo) pairs + f32 fix-up",
+                                 "threshold_factor": round(4.0 * 8.0 / 6.0, 3), "device_side_net": True, "fixup": ctx.fixup_stats(),
+                                 "equals_reference_arithmetic": equal16,
+                                 "equals_refbytes_output": bool(np.array_equal(rb, rb16)),
+                                 "note": "opt-in mode outside the float32 north star: never the headline"}
             ctx.set_mode(S.MODE_MFMA)
             ctx.set_seam_deferral(deferral)
         emit_line(out)

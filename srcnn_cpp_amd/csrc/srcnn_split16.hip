@@ -79,6 +79,15 @@ constexpr int SP_RS = 264;                      // ring row pitch in halfs: ever
 constexpr int SP_CS = 2 * YR * SP_RS + 32;
 constexpr int SP_RING_BYTES = 2 * SP_CS * 2;
 
+// A pointer every lane holds the same value of, moved to scalar registers explicitly.
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr16(T *p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 // FIX: SRCNN_MODE_REFBYTES16 -- a flag byte beside every output byte (fix_code(), srcnn_kernels.h) for the exact fix-up kernels.
 template <bool PRE, bool DIAG = false, bool FIX = false>
 __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripParams p)
@@ -205,8 +214,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
         uint8_t *d8 = ok ? p.dst + o : reinterpret_cast<uint8_t *>(p.sink) + lane;
         *d8 = (uint8_t)clampi16((int)v, 0, 255);                          // src/srcnn.cpp:238-240
         if constexpr (FIX) {
-            uint8_t *f8 = ok ? p.flag + o : reinterpret_cast<uint8_t *>(p.sink) + 512 + lane;
-            *f8 = fix_code(v, p.fix_delta, p.fix_scale);
+            // scalar row base + the lane's column (one saddr-form store): a second selected 64-bit address per lane is what made
+            // this instantiation spill 48 registers to scratch and run at half the speed of the plain one
+            const long orow = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride;      // uniform
+            __attribute__((address_space(1))) uint8_t *frow = (__attribute__((address_space(1))) uint8_t *)uniform_ptr16(p.flag + orow);
+            asm volatile("" : "+s"(frow));
+            unsigned col = (unsigned)gx;
+            asm volatile("" : "+v"(col));
+            if (ok) frow[col] = fix_code(v, p.fix_delta, p.fix_scale);
         }
         if constexpr (PRE) {
             float *dp = ok ? p.pre + o : p.sink + 64 + lane;
@@ -475,8 +490,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
         hp_use(f - 2, 0, true);
     }
     if (f - 1 >= f_lo) {
-        vertical(f - 1, last_in_a ? tA : tB);
-        if (f - 1 == H - 1) vertical_bottom(f - 1, last_in_a ? tA : tB);
+        // (a select of VALUES: selecting between references to tA and tB made the FIX instantiation keep both in scratch memory,
+        // with 44 scratch accesses inside the row loop -- 503 us per 3840x2160 plane instead of 272)
+        if constexpr (FIX) {
+            f32x16 tl;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tl[q] = last_in_a ? tA[q] : tB[q];
+            vertical(f - 1, tl);
+            if (f - 1 == H - 1) vertical_bottom(f - 1, tl);
+        } else {                           // (the other instantiations: their listings stay what rounds 1-4 measured)
+            vertical(f - 1, last_in_a ? tA : tB);
+            if (f - 1 == H - 1) vertical_bottom(f - 1, last_in_a ? tA : tB);
+        }
         __syncthreads();
         const int g = f - 1;
         const int nslots = (g == H - 1) ? 3 : 1;

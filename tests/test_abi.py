@@ -268,3 +268,21 @@ def test_python_binding_rejects_mismatched_shapes():
         ctx.forward_y_frames(frames, out=ro)
     with pytest.raises(ValueError):
         ctx.forward_y_frames(np.zeros((0, 8, 8), np.uint8))
+
+
+@pytest.mark.parametrize("unit", ["srcnn_mfma.hip", "srcnn_split16.hip", "srcnn_exact.hip"])
+def test_no_kernel_keeps_registers_in_scratch_memory(tmp_path, unit):
+    """A kernel that spills -- or keeps an array behind a selected reference in private memory -- pays for it at dispatch and in
+    every row: the REFBYTES16 instantiation of the split-f16 strip kernel ran at 503 us per 3840x2160 plane instead of 272 for
+    four rounds because `last ? tA : tB` on two accumulator tiles sent both to scratch (round 5).  Every kernel of the three hot
+    translation units must report a private segment of 0 bytes, with the flags the build uses."""
+    import re
+    import subprocess
+    flags = [u[1] for u in B.UNITS if u[0] == unit and len(u) == 2][0]
+    out = tmp_path / "unit.s"
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, f"-I{B.CSRC}", "-S", "--cuda-device-only",
+                    "-o", str(out), str(B.CSRC / unit)], check=True, stderr=subprocess.DEVNULL)
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", out.read_text(), re.S)
+    assert len(kernels) >= 4
+    for name, body in kernels:
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1)) == 0, name
