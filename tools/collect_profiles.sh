@@ -15,5 +15,6 @@ done
 [ -f $SRC/fix_apply_ab_final.txt ] && grep -v "amdgpu.ids" $SRC/fix_apply_ab_final.txt > $DST/fix_apply_ab_final.txt
 [ -f $SRC/seam_deferral_ab_final.txt ] && grep -v "amdgpu.ids" $SRC/seam_deferral_ab_final.txt > $DST/seam_deferral_ab_final.txt
 for f in $SRC/trace_refbytes/*kernel_stats.csv; do [ -f "$f" ] && cp $f $DST/refbytes_4k_kernel_stats.csv; done
+for f in $SRC/trace_refbytes16/*kernel_stats.csv; do [ -f "$f" ] && cp $f $DST/refbytes16_4k_kernel_stats.csv; done
 [ -f $SRC/pmc_traffic.json ] && cp $SRC/pmc_traffic.json profiles/pmc_traffic.json
 ls $DST

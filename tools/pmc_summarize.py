@@ -163,7 +163,7 @@ with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
 
 # per-kernel averages of the other runs (rocprofv3 --stats): OUTDIR/other_kernels_stats.csv
 rows = [["run", "kernel", "calls", "avg_us"]]
-for tag in ("unfused", "pipeline", "exact", "pipeline_split16", "refbytes"):
+for tag in ("unfused", "pipeline", "exact", "pipeline_split16", "refbytes", "refbytes16"):
     for f in glob.glob(os.path.join(out, f"trace_{tag}", "**", "*kernel_stats.csv"), recursive=True):
         with open(f, newline="") as fh:
             for r in list(csv.reader(fh))[1:]:

@@ -42,7 +42,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU 
       python3 $ROOT/bench.py --path unfused --steps 3 --warmup 1 --prewarm-ms 0 --no-cpu-baseline ) > $OUT/pmc_unfused_$tag.log 2>&1
 done
 # the other kernels: unfused path (layer-1/2 kernel + layer-3 kernel), pipeline byte kernels, exact kernels
-for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20" "refbytes --mode refbytes --steps 20"; do
+for cfg in "unfused --path unfused --frames 8 --steps 5" "pipeline --path pipeline --steps 20" "exact --mode exact --steps 5" "pipeline_split16 --path pipeline --mode split16 --steps 20" "refbytes --mode refbytes --steps 20" "refbytes16 --mode refbytes16 --steps 20"; do
   set -- $cfg; tag=$1; shift
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$tag -o trace -- \
       python3 $ROOT/bench.py "$@" --warmup 1 --no-cpu-baseline ) > $OUT/trace_$tag.log 2>&1
