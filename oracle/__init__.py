@@ -205,16 +205,41 @@ def gpuorder_conv99x11(src, k99, b99, k11, b11):
     return _conv99x11(lib().srcnn_gpuorder_conv99x11, src, k99, b99, k11, b11)
 
 
-def _forward(fn, src, blob):
-    src, ps = _u8(src)
+anomalies = 0          # how often two runs of the same call disagreed in this process (see _forward)
+
+
+def _forward_once(fn, src, ps, blob, pw):
     h, w = src.shape
-    blob, pw = _f32(blob)
-    assert blob.size == N_WEIGHTS
     dst = np.empty((h, w), np.uint8)
     pre = np.empty((h, w), np.float32)
     rc = fn(ps, w, dst.ctypes.data_as(_u8p), w, w, h, pw, pre.ctypes.data_as(_f32p))
     assert rc == 0
     return dst, pre
+
+
+def _forward(fn, src, blob):
+    """A checker must not be the weak link: on the GPU boxes' shared 256-thread hosts one call in ~5,000 of the OpenMP loops
+    on a SMALL plane returned a band of rows computed from wrong intermediate data (profiles/r05/soak_long.txt; cause not
+    found, never seen in the 8-CPU build container).  On hosts with more than 32 logical CPUs planes up to a megapixel are
+    therefore computed twice -- a fraction of a second -- and a third time if the two runs disagree; the majority is returned
+    and the disagreement counted in `anomalies`."""
+    global anomalies
+    src, ps = _u8(src)
+    blob, pw = _f32(blob)
+    assert blob.size == N_WEIGHTS
+    a = _forward_once(fn, src, ps, blob, pw)
+    if src.size > (1 << 20) or (os.cpu_count() or 1) <= 32:         # (large shared hosts only: where it was seen)
+        return a
+    b = _forward_once(fn, src, ps, blob, pw)
+    if np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]):
+        return a
+    anomalies += 1
+    c = _forward_once(fn, src, ps, blob, pw)
+    if np.array_equal(c[0], a[0]) and np.array_equal(c[1], a[1]):
+        return a
+    if np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1]):
+        return b
+    raise RuntimeError("oracle: three runs of the same call gave three different results")
 
 
 def forward_y(src, blob):

@@ -72,4 +72,5 @@ while time.time() - t0 < budget:
 print(f"soak_models ok: {n} random models x planes in {time.time() - t0:.0f} s ({n16} of them also in REFBYTES16); every plane bytewise equal "
       f"to the reference arithmetic; largest monitored deviation / threshold = {worst:.3f} (REFBYTES16: {worst16:.3f}); "
       f"{reruns} launches were over delta / 2 and redone by the device-side net"
-      + (f"; ORACLE ANOMALIES (first run of oracle.forward_y disagreed with a second run AND with the GPU; (n, w, h, bytes, rows)): {oracle_flakes}" if oracle_flakes else ""))
+      + (f"; ORACLE ANOMALIES (first run of oracle.forward_y disagreed with a second run AND with the GPU; (n, w, h, bytes, rows)): {oracle_flakes}" if oracle_flakes else "")
+      + f"; the oracle wrapper's own double runs disagreed {oracle.anomalies} times")
