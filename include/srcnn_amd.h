@@ -86,7 +86,7 @@ enum {
  *   SRCNN_MODE_REFBYTES16 opt-in, like SPLIT16 outside the float32 north star: the same flag-and-recompute
  *                    scheme behind the split-f16 kernel (threshold 8/6 of REFBYTES': that kernel's noise is a
  *                    little wider).  The reference's bytes at 0.52-0.56 of the float32 MFMA mode's TIME
- *                    (0.49-0.53 ms per 3840x2160 plane on one MI355X). */
+ *                    (0.49-0.55 ms per 3840x2160 plane on one MI355X). */
 enum { SRCNN_MODE_MFMA = 0, SRCNN_MODE_EXACT = 1, SRCNN_MODE_SPLIT16 = 2, SRCNN_MODE_REFBYTES = 3, SRCNN_MODE_REFBYTES16 = 4 };
 
 typedef struct srcnn_ctx srcnn_ctx;
