@@ -389,6 +389,8 @@ def parse_args():
                          "launch per step (rounds 1-4).  Same bytes.")
     ap.add_argument("--no-stripe-leg", action="store_true",
                     help="N > 1, frames workload: skip the row-striped 7680x4320 plane (configs[3], ms per image) that rides on the line as `stripe`")
+    ap.add_argument("--stripe-timeout-s", type=float, default=240.0,
+                    help="N > 1: seconds the row-striped leg behind the frames figure may take before its watchdog prints the line without it (0 = no watchdog)")
     ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -410,6 +412,7 @@ def parse_args():
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)        # another build of the library (tools/ab.sh, the tuning build)
     ap.add_argument("--plpad", type=int, default=0, help=argparse.SUPPRESS)   # experiment: floats added to the unfused workspace's plane pitch (tuning build)
     ap.add_argument("--fault-rank", type=int, default=-1, help=argparse.SUPPRESS)      # test hook: this rank exits 7 before the rendezvous
+    ap.add_argument("--hang-stripe-rank", type=int, default=-1, help=argparse.SUPPRESS)    # test hook: this rank never enters the stripe leg (its watchdog's test)
     ap.add_argument("--shared-gpu", action="store_true",
                     help="smoke-test aid: every rank uses GPU 0 (1-GPU box, use with --backend gloo)")
     return ap.parse_args()
@@ -685,9 +688,10 @@ def worker(args):
     # The OTHER half of the metric ("MPix/s AND ms/image at 1/2/4/8"): ms per image at N > 1 is ONE plane row-striped over the
     # ranks (BASELINE configs[3]).  The driver's one command per N is the frames workload above; this leg rides on it, after
     # its timed region, so that the same line carries both curves.  Never `value`.
+    # (It runs LAST, behind the assembly of the line below, under a watchdog: transports that have only ever run with the ranks
+    # sharing one GPU must not be able to take the measured frames figure with them if they hang on a real node.)
     stripe_obj = None
-    if (world > 1 and not stripe and args.path == "fused" and args.mode == "mfma" and F == 1 and not args.no_stripe_leg):
-        stripe_obj = stripe_leg(args, S, torch, dist, ctx, world, rank, timed, make_rccl)
+    out = None
 
     if rank == 0:
         pix_per_step = W * H if stripe else W * H * F * world
@@ -760,8 +764,6 @@ def worker(args):
                                    "H2D + kernel + D2H of neighbouring frames overlapped on two lanes" if F > 1 else ": row bands")}
         if pmc_ref:
             out["pmc_reference"] = pmc_ref
-        if stripe_obj is not None:
-            out["stripe"] = stripe_obj
         if world > 1:
             out["degraded"] = bool(degraded)
             out["distributed"] = {"control_plane": "gloo", "rccl_world": rccl_world,
@@ -887,6 +889,33 @@ def worker(args):
                                  "note": "opt-in mode outside the float32 north star: never the headline"}
             ctx.set_mode(S.MODE_MFMA)
             ctx.set_seam_deferral(deferral)
+
+    if (world > 1 and not stripe and args.path == "fused" and args.mode == "mfma" and F == 1 and not args.no_stripe_leg):
+        import threading
+
+        def give_up():
+            # runs on the timer's thread while the main thread sits in a collective or a synchronize that does not return:
+            # no GPU call, no collective here -- print what was measured and leave
+            if rank == 0:
+                out["stripe"] = {"error": f"the stripe leg did not finish within {args.stripe_timeout_s:g} s and was abandoned "
+                                          "(a transport hung); the frames figure above is unaffected",
+                                 "degraded": True, "degraded_why": ["stripe leg abandoned by its watchdog"]}
+                emit_line(out)
+            os._exit(0)
+
+        guard = None
+        if args.stripe_timeout_s > 0:
+            guard = threading.Timer(args.stripe_timeout_s, give_up)
+            guard.daemon = True
+            guard.start()
+        if rank == args.hang_stripe_rank:       # test hook: the other ranks wait for this one in the leg's first collective
+            time.sleep(1e6)
+        stripe_obj = stripe_leg(args, S, torch, dist, ctx, world, rank, timed, make_rccl)
+        if guard is not None:
+            guard.cancel()
+        if rank == 0:
+            out["stripe"] = stripe_obj
+    if rank == 0:
         emit_line(out)
 
     if stripe and isinstance(stepper, sharding.PeerStripeStep):

@@ -319,6 +319,20 @@ def test_bench_frames_line_carries_the_striped_plane():
     assert "stripe" not in off
 
 
+def test_a_hung_stripe_leg_does_not_take_the_frames_figure_with_it():
+    """The stripe leg's transports have only ever run with the ranks sharing one GPU.  If one of them hangs on a real node the
+    watchdog of the leg prints the line with the measured frames figure and an error in `stripe`, and every rank leaves with 0
+    -- instead of the launcher's (or the driver's) time limit taking the whole line.  Rank 1 never enters the leg here; rank 0
+    waits for it in the leg's first collective."""
+    import time
+    t = time.time()
+    d = run_bench("--gpus", 2, "--shared-gpu", "--backend", "gloo", "--width", 1280, "--height", 720, "--stripe-timeout-s", 6,
+                  "--hang-stripe-rank", 1)
+    assert time.time() - t < 120
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["config"]["output_crc32"]) == 2
+    assert "abandoned" in d["stripe"]["error"] and d["stripe"]["degraded"] is True
+
+
 def test_peer_stripes_stream_planes_without_a_barrier(gpu_ctx, tmp_path):
     """`sharding.PeerStripeStep` streams NEW planes without a barrier per plane -- two stripe allocations per
     rank used in turn (both mapped by the neighbours once), `upload(k + 1)` while plane k computes, and only neighbour-to-
