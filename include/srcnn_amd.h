@@ -372,8 +372,8 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
  *
  * WHAT THE MODE GUARANTEES.  Its bytes are the reference's wherever |v_mfma - v_reference| <= delta.  delta is not a proven
  * bound of that rounding noise (the rigorous one is ~10 grey levels): it is 4 x the noise scale of the loaded model (+ an
- * absolute term), 3.1 x the largest deviation met on 54 MPix of content and 2.1 x the largest an adversarial search over
- * receptive fields found (profiles/r04/fixup_adversarial.txt: 6.4e-4 = 0.47 delta for the shipped model).  So the guarantee is
+ * absolute term), 3.1 x the largest deviation met on 54 MPix of content and 1.7 x the largest adversarial searches over
+ * receptive fields found (profiles/r05/adversarial_gpu.txt: 7.9e-4 = 0.58 delta for the shipped model).  So the guarantee is
  * CONDITIONAL on max_dev < delta, and the library ACTS on the condition:
  *   srcnn_set_fixup_strict(ctx, on) ON BY DEFAULT.  A kernel queued behind the recomputation unconditionally compares the
  *                                   launch's max_dev with delta / 2 and, when it is exceeded, redoes the launch's rows in the

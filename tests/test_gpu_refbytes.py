@@ -243,8 +243,8 @@ def test_pipeline_reproduces_the_reference_picture(weights_blob, mode):
 def test_adversarial_windows_keep_the_reference_bytes(ref_ctx, weights_blob):
     """The windows an adversarial search drove to the largest |v_mfma - v_reference| (tests/checks/fixup_adversarial.py,
     150,000 restarts on the CPU models; profiles/r04/fixup_adversarial.txt), tiled into one plane: both REFBYTES modes return
-    the reference's bytes, the monitor stays below half the threshold (the worst window sits at 0.47 of round 5's delta: just
-    below the point where the device-side re-run would take over), and in the MFMA mode the centre pixels carry exactly the
+    the reference's bytes, the monitor stays below half the threshold (the worst of THESE windows sits at 0.47 of round 5's delta;
+    the GPU-side search of round 5 went further: next test), and in the MFMA mode the centre pixels carry exactly the
     value the search predicted (the CPU model it searched IS the kernel's arithmetic)."""
     from test_adversarial import FIX, tile_windows
     fx = np.load(FIX)
@@ -261,6 +261,35 @@ def test_adversarial_windows_keep_the_reference_bytes(ref_ctx, weights_blob):
         assert np.array_equal(pre[cy, cx], fx["shipped_vals"][:, 1])
         # the worst window found sits at 0.47 delta: the monitor sees deviations of that size when such a pixel is flagged
         assert np.abs(pre[cy, cx] - fx["shipped_vals"][:, 0]).max() > 0.4 * st["delta"]
+
+
+def test_windows_of_the_gpu_side_search_keep_the_reference_bytes(weights_blob):
+    """tests/checks/adversarial_gpu.py (round 5) searched on the GPU itself, 35 million window evaluations per kernel: the float32
+    MFMA kernel reaches 7.9e-4 = 0.58 of REFBYTES' threshold, the split-f16 kernel 1.13e-3 = 0.62 of REFBYTES16's.  The committed
+    windows (tests/golden/adversarial_windows_gpu.npz), tiled into one plane: each kernel shows exactly the recorded deviation at
+    its windows' centres, and both byte-exact modes return the reference's bytes."""
+    from test_adversarial import FIX_GPU, tile_windows
+    fx = np.load(FIX_GPU)
+    wins = np.concatenate([fx["mfma_windows"], fx["split16_windows"]])
+    n_m = len(fx["mfma_windows"])
+    plane, cy, cx = tile_windows(wins)
+    r_out, r_pre = oracle.forward_y(plane, weights_blob)
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        for mode, sl, rec in ((S.MODE_MFMA, slice(0, n_m), fx["mfma_dev"]), (S.MODE_SPLIT16, slice(n_m, None), fx["split16_dev"])):
+            ctx.set_mode(mode)
+            pre = np.empty(plane.shape, np.float32)
+            ctx.forward_y(plane, preclamp=pre)
+            dev = np.abs(pre[cy, cx].astype(np.float64) - r_pre[cy, cx])[sl]
+            assert np.allclose(dev, rec, rtol=0, atol=1e-7), (mode, dev, rec)
+    for mode, rec in ((S.MODE_REFBYTES, fx["mfma_dev"]), (S.MODE_REFBYTES16, fx["split16_dev"])):
+        with S.Context(0) as ctx:
+            ctx.set_weights_blob(weights_blob)
+            ctx.set_mode(mode)
+            assert np.array_equal(ctx.forward_y(plane), r_out), mode
+            st = ctx.fixup_stats()
+            # the largest deviation any search has produced for the mode's kernel keeps a factor 1.5 below the mode's threshold
+            assert st["exact_reruns"] == 0 and float(rec.max()) < st["delta"] / 1.5, (mode, st)
 
 
 @pytest.mark.parametrize("k", range(8))
