@@ -13,7 +13,7 @@ grew.  Starts: random noise, flat + noise, saturated patterns, and round 4's wor
 Afterwards the plane of the worst windows found goes through SRCNN_MODE_REFBYTES and REFBYTES16: the bytes must be the
 reference's and the monitored deviation is reported against the thresholds in use.
 
-usage: python tests/checks/adversarial_gpu.py [seconds per mode = 120] [G = 100] [seed = 1]
+usage: python tests/checks/adversarial_gpu.py [seconds per mode = 120] [G = 100] [seed = 1] [fresh]
 """
 import sys
 import time
@@ -42,6 +42,7 @@ def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     g = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    fresh = len(sys.argv) > 4 and sys.argv[4] == "fresh"         # do not start from this search's own earlier windows
     rng = np.random.default_rng(seed)
     blob = S.load_weights()
     n = g * g
@@ -56,9 +57,11 @@ def main():
         w[k:2 * k] = np.clip(base + rng.integers(-6, 7, (k, R, R)), 0, 255).astype(np.uint8)          # flat + noise
         w[2 * k:3 * k] = np.where(rng.random((k, R, R)) < rng.random((k, 1, 1)), 255, 0).astype(np.uint8)   # saturated patterns
         gold = np.load(ROOT / "tests" / "golden" / "adversarial_windows.npz")["shipped_windows"]
+        if fresh:
+            gold = gold[:0]
         w[3 * k:3 * k + len(gold)] = gold                                                                # round 4's worst
         mine = ROOT / "tests" / "golden" / "adversarial_windows_gpu.npz"                                 # ... and this search's own
-        if mine.exists():
+        if mine.exists() and not fresh:
             prev = np.load(mine)
             prev = np.concatenate([prev["mfma_windows"], prev["split16_windows"]])
             reps = np.repeat(prev, 40, 0)                                                                # 40 climbers start from each
