@@ -795,100 +795,113 @@ def worker(args):
                                     "executed_frac": round(achieved * 43008 / S.FLOP_PER_PIXEL / peak16, 4),
                                     "vs_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4)})
         if world == 1 and args.path == "fused" and not stripe and args.sustained_s > 0 and not args.no_cpu_baseline:     # (--no-cpu-baseline marks a quick run)
-            # The timed region is K = 20-50 steps, 20-50 ms of load.  What the device sustains over SECONDS: the same step queued
-            # back to back in chunks of 200, every chunk between two events on the kernels' stream.
-            chunk, per_chunk, t_s = 200, [], time.perf_counter()
-            while time.perf_counter() - t_s < args.sustained_s:
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(stream)
-                for _ in range(chunk):
-                    step()
-                if deferral:
-                    ctx.flush()
-                eb.record(stream)
-                eb.synchronize()
-                per_chunk.append(ea.elapsed_time(eb) / chunk)
-            ms_s = sum(per_chunk) / len(per_chunk)
-            out["sustained"] = {"seconds": round(time.perf_counter() - t_s, 2), "steps": chunk * len(per_chunk),
-                                "ms_per_step": round(ms_s, 4), "value": round(W * H * F / ms_s / 1e3, 2), "unit": "MPix/s",
-                                "frac": round(S.FLOP_PER_PIXEL * W * H * F / (ms_s * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                "slowest_chunk_ms_per_step": round(max(per_chunk), 4), "fastest_chunk_ms_per_step": round(min(per_chunk), 4),
-                                "what": f"the same step back to back for {args.sustained_s:g} s in chunks of {chunk}, HIP events per chunk; never `value`"}
+            try:
+                # The timed region is K = 20-50 steps, 20-50 ms of load.  What the device sustains over SECONDS: the same step queued
+                # back to back in chunks of 200, every chunk between two events on the kernels' stream.
+                chunk, per_chunk, t_s = 200, [], time.perf_counter()
+                while time.perf_counter() - t_s < args.sustained_s:
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record(stream)
+                    for _ in range(chunk):
+                        step()
+                    if deferral:
+                        ctx.flush()
+                    eb.record(stream)
+                    eb.synchronize()
+                    per_chunk.append(ea.elapsed_time(eb) / chunk)
+                ms_s = sum(per_chunk) / len(per_chunk)
+                out["sustained"] = {"seconds": round(time.perf_counter() - t_s, 2), "steps": chunk * len(per_chunk),
+                                    "ms_per_step": round(ms_s, 4), "value": round(W * H * F / ms_s / 1e3, 2), "unit": "MPix/s",
+                                    "frac": round(S.FLOP_PER_PIXEL * W * H * F / (ms_s * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    "slowest_chunk_ms_per_step": round(max(per_chunk), 4), "fastest_chunk_ms_per_step": round(min(per_chunk), 4),
+                                    "what": f"the same step back to back for {args.sustained_s:g} s in chunks of {chunk}, HIP events per chunk; never `value`"}
+            except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
+                out["sustained"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and args.path == "fused" and not stripe and not args.no_e2e:
-            # SURVEY 8d's secondary metric, never `value`: the same planes from and to HOST memory, PCIe-inclusive
-            # (srcnn_forward_y_frames: pinned staging, uploads / kernels / downloads of neighbouring frames overlapped).
-            n_e2e = 16                                         # (fill and drain of the two-lane pipeline are 0.6 ms: 7 % of 8 frames)
-            hf = np.ascontiguousarray(np.broadcast_to(frames[0], (n_e2e,) + frames[0].shape))
-            ho = np.empty_like(hf)
-            ctx.set_stream(0)                                  # the context's own stream
-            ctx.forward_y_frames(hf, out=ho)                   # staging buffers, pinned memory
-            reps, t_e = 3, time.perf_counter()
-            for _ in range(reps):
-                ctx.forward_y_frames(hf, out=ho)
-            dt = (time.perf_counter() - t_e) / reps
-            out["e2e"] = {"value": round(W * H * n_e2e / dt / 1e6, 2), "unit": "MPix/s", "ms_per_frame": round(dt / n_e2e * 1e3, 4),
-                          "what": f"{n_e2e} x {W}x{H} host frames through srcnn_forward_y_frames, pageable caller memory, H2D + "
-                                  f"kernel + D2H overlapped on two lanes; mean of {reps} passes",
-                          "output_equals_resident": bool(zlib.crc32(ho[n_e2e - 1].tobytes()) == crcs[0])}
+            try:
+                # SURVEY 8d's secondary metric, never `value`: the same planes from and to HOST memory, PCIe-inclusive
+                # (srcnn_forward_y_frames: pinned staging, uploads / kernels / downloads of neighbouring frames overlapped).
+                n_e2e = 16                                         # (fill and drain of the two-lane pipeline are 0.6 ms: 7 % of 8 frames)
+                hf = np.ascontiguousarray(np.broadcast_to(frames[0], (n_e2e,) + frames[0].shape))
+                ho = np.empty_like(hf)
+                ctx.set_stream(0)                                  # the context's own stream
+                ctx.forward_y_frames(hf, out=ho)                   # staging buffers, pinned memory
+                reps, t_e = 3, time.perf_counter()
+                for _ in range(reps):
+                    ctx.forward_y_frames(hf, out=ho)
+                dt = (time.perf_counter() - t_e) / reps
+                out["e2e"] = {"value": round(W * H * n_e2e / dt / 1e6, 2), "unit": "MPix/s", "ms_per_frame": round(dt / n_e2e * 1e3, 4),
+                              "what": f"{n_e2e} x {W}x{H} host frames through srcnn_forward_y_frames, pageable caller memory, H2D + "
+                                      f"kernel + D2H overlapped on two lanes; mean of {reps} passes",
+                              "output_equals_resident": bool(zlib.crc32(ho[n_e2e - 1].tobytes()) == crcs[0])}
+            except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
+                out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, H)
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, H)
+            except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and args.path == "fused" and args.mode == "mfma" and not stripe and not args.no_refbytes:
-            # The same step in SRCNN_MODE_REFBYTES (the MFMA kernel + exact recomputation of the pixels next to a truncation
-            # boundary): its time, what the fix-up did, and -- against the sha256 the cpu_baseline leg's oracle made of the same
-            # frame -- whether the bytes ARE the reference arithmetic's.  Never `value`.
-            import hashlib
-            ctx.set_stream(stream.cuda_stream)
+            try:
+                # The same step in SRCNN_MODE_REFBYTES (the MFMA kernel + exact recomputation of the pixels next to a truncation
+                # boundary): its time, what the fix-up did, and -- against the sha256 the cpu_baseline leg's oracle made of the same
+                # frame -- whether the bytes ARE the reference arithmetic's.  Never `value`.
+                import hashlib
+                ctx.set_stream(stream.cuda_stream)
 
-            def wall(n_steps):
-                for _ in range(10):
-                    step()
-                ctx.flush()
-                torch.cuda.synchronize()
-                t_r = time.perf_counter()
-                for _ in range(n_steps):
-                    step()
-                ctx.flush()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t_r) / n_steps
-            # the MFMA mode launched the way REFBYTES launches (a seam launch per step: the fix-up needs every flag of a plane
-            # before it starts, so REFBYTES steps cannot defer theirs): the like-for-like denominator beside the headline's
-            ctx.set_seam_deferral(False)
-            dt_plain = wall(args.steps)
-            ctx.set_mode(S.MODE_REFBYTES)
-            dt_r = wall(args.steps)
-            rb = d_out.cpu().numpy()
-            ref = (out.get("cpu_baseline") or {}).get("reference_output") or {}
-            rows = int(ref.get("rows", 0))
-            equal = None
-            if 0 < rows <= H:
-                # a slab of the top `rows` rows of the plane is exact away from its cut: compare all but its last 6 rows' worth
-                # when it is a crop, the whole plane when it is the whole plane
+                def wall(n_steps):
+                    for _ in range(10):
+                        step()
+                    ctx.flush()
+                    torch.cuda.synchronize()
+                    t_r = time.perf_counter()
+                    for _ in range(n_steps):
+                        step()
+                    ctx.flush()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t_r) / n_steps
+                # the MFMA mode launched the way REFBYTES launches (a seam launch per step: the fix-up needs every flag of a plane
+                # before it starts, so REFBYTES steps cannot defer theirs): the like-for-like denominator beside the headline's
+                ctx.set_seam_deferral(False)
+                dt_plain = wall(args.steps)
+                ctx.set_mode(S.MODE_REFBYTES)
+                dt_r = wall(args.steps)
+                rb = d_out.cpu().numpy()
+                ref = (out.get("cpu_baseline") or {}).get("reference_output") or {}
+                rows = int(ref.get("rows", 0))
+                equal = None
+                if 0 < rows <= H:
+                    # a slab of the top `rows` rows of the plane is exact away from its cut: compare all but its last 6 rows' worth
+                    # when it is a crop, the whole plane when it is the whole plane
+                    if rows == H:
+                        equal = hashlib.sha256(np.ascontiguousarray(rb[0]).tobytes()).hexdigest() == ref.get("sha256")
+                out["refbytes"] = {"ms_per_step": round(dt_r * 1e3, 4), "value": round(W * H * F / dt_r / 1e6, 2), "unit": "MPix/s",
+                                   "vs_mfma_mode": round(dt_r / (elapsed / args.steps), 3),
+                                   "vs_mfma_mode_without_seam_deferral": round(dt_r / dt_plain, 3), "mfma_without_seam_deferral_ms": round(dt_plain * 1e3, 4),
+                                   "threshold_factor": 4.0, "device_side_net": True, "fixup": ctx.fixup_stats(),
+                                   "equals_reference_arithmetic": equal,
+                                   "checked_against": "sha256 of oracle.forward_y on the same frame (cpu_baseline leg)" if equal is not None
+                                                      else "not checked (no whole-plane oracle output in this run)"}
+                # ... and in SRCNN_MODE_REFBYTES16: the same fix-up and the same device-side net behind the split-f16 strip kernel
+                # (opt-in: f16 MFMAs on (hi, lo) operand pairs carry the pass, the float32 reference arithmetic decides every byte
+                # next to a truncation boundary) -- the reference's bytes again, checked against the same sha256.  Never `value`.
+                ctx.set_mode(S.MODE_REFBYTES16)
+                dt_r16 = wall(args.steps)
+                rb16 = d_out.cpu().numpy()
+                equal16 = None
                 if rows == H:
-                    equal = hashlib.sha256(np.ascontiguousarray(rb[0]).tobytes()).hexdigest() == ref.get("sha256")
-            out["refbytes"] = {"ms_per_step": round(dt_r * 1e3, 4), "value": round(W * H * F / dt_r / 1e6, 2), "unit": "MPix/s",
-                               "vs_mfma_mode": round(dt_r / (elapsed / args.steps), 3),
-                               "vs_mfma_mode_without_seam_deferral": round(dt_r / dt_plain, 3), "mfma_without_seam_deferral_ms": round(dt_plain * 1e3, 4),
-                               "threshold_factor": 4.0, "device_side_net": True, "fixup": ctx.fixup_stats(),
-                               "equals_reference_arithmetic": equal,
-                               "checked_against": "sha256 of oracle.forward_y on the same frame (cpu_baseline leg)" if equal is not None
-                                                  else "not checked (no whole-plane oracle output in this run)"}
-            # ... and in SRCNN_MODE_REFBYTES16: the same fix-up and the same device-side net behind the split-f16 strip kernel
-            # (opt-in: f16 MFMAs on (hi, lo) operand pairs carry the pass, the float32 reference arithmetic decides every byte
-            # next to a truncation boundary) -- the reference's bytes again, checked against the same sha256.  Never `value`.
-            ctx.set_mode(S.MODE_REFBYTES16)
-            dt_r16 = wall(args.steps)
-            rb16 = d_out.cpu().numpy()
-            equal16 = None
-            if rows == H:
-                equal16 = hashlib.sha256(np.ascontiguousarray(rb16[0]).tobytes()).hexdigest() == ref.get("sha256")
-            out["refbytes16"] = {"ms_per_step": round(dt_r16 * 1e3, 4), "value": round(W * H * F / dt_r16 / 1e6, 2), "unit": "MPix/s",
-                                 "vs_mfma_mode": round(dt_r16 / (elapsed / args.steps), 3), "dtype": "f16 (hi, lo) pairs + f32 fix-up",
-                                 "threshold_factor": round(4.0 * 8.0 / 6.0, 3), "device_side_net": True, "fixup": ctx.fixup_stats(),
-                                 "equals_reference_arithmetic": equal16,
-                                 "equals_refbytes_output": bool(np.array_equal(rb, rb16)),
-                                 "note": "opt-in mode outside the float32 north star: never the headline"}
-            ctx.set_mode(S.MODE_MFMA)
-            ctx.set_seam_deferral(deferral)
+                    equal16 = hashlib.sha256(np.ascontiguousarray(rb16[0]).tobytes()).hexdigest() == ref.get("sha256")
+                out["refbytes16"] = {"ms_per_step": round(dt_r16 * 1e3, 4), "value": round(W * H * F / dt_r16 / 1e6, 2), "unit": "MPix/s",
+                                     "vs_mfma_mode": round(dt_r16 / (elapsed / args.steps), 3), "dtype": "f16 (hi, lo) pairs + f32 fix-up",
+                                     "threshold_factor": round(4.0 * 8.0 / 6.0, 3), "device_side_net": True, "fixup": ctx.fixup_stats(),
+                                     "equals_reference_arithmetic": equal16,
+                                     "equals_refbytes_output": bool(np.array_equal(rb, rb16)),
+                                     "note": "opt-in mode outside the float32 north star: never the headline"}
+                ctx.set_mode(S.MODE_MFMA)
+                ctx.set_seam_deferral(deferral)
+            except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
+                out.setdefault("refbytes", {"error": f"{type(e).__name__}: {str(e)[:300]}"})
+                out.setdefault("refbytes16", {"error": f"{type(e).__name__}: {str(e)[:300]}"})
 
     if (world > 1 and not stripe and args.path == "fused" and args.mode == "mfma" and F == 1 and not args.no_stripe_leg):
         import threading
