@@ -72,11 +72,14 @@ int main(int argc, char **argv)
                 for (int row_begin : {0, 1000})
                     for (int skew : {0, 10, 35, 99})
                         for (int wpc : {1, 2})
-                            for (int seams : {0, 1}) {
+                            for (int seams : {0, 1})
+                              for (int edges : {0, 2 * 16 + 2 * 256, 2 * 16, 2 * 256}) {     // the planner's edge-row weights ride in the upper bits
+                                if (edges && (wpc != 2 || !seams || skew != 10 || n_cu < 64)) continue;   // (only the balanced planner takes them; the product's skew)
+                                if (edges && edges != 2 * 16 + 2 * 256 && n_cu != 256) continue;           // (one-sided: the product's CU count only)
                                 int n_seams = -1;
                                 const int cap = wpc * n_cu;
                                 std::vector<int> items((size_t)srcnn::ITEM_INTS * cap), sm((size_t)2 * cap);
-                                const int n = srcnn_debug_plan_items(n_cu, n_strips, row_begin, row_begin + rows, skew, wpc, seams,
+                                const int n = srcnn_debug_plan_items(n_cu, n_strips, row_begin, row_begin + rows, skew, wpc + edges, seams,
                                                                      items.data(), cap, sm.data(), cap, &n_seams);
                                 ++plans;
                                 CHECK(n >= 0 && n <= cap && n_seams >= 0 && n_seams <= cap);
