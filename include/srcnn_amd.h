@@ -115,7 +115,11 @@ int srcnn_synchronize(srcnn_ctx *ctx);
  * the work items of the context's NEXT such launch on the same stream, in the tail where compute units would otherwise idle.
  * CONTRACT: the last launch's output is complete on the stream only after srcnn_flush(ctx) (queues the pending seam work, does not
  * wait) or after ANY other call on the context (srcnn_synchronize included) -- a caller that enqueues its own work reading the
- * output calls srcnn_flush first.  Same bytes either way.  Off by default; SRCNN_MODE_MFMA only (the other modes ignore it). */
+ * output calls srcnn_flush first.  The next deferred launch itself does NOT complete the previous output (it carries that
+ * output's seam blocks beside its own work items; the output is complete when THAT kernel has finished).  A next launch that
+ * READS the previous output -- as its src or as a halo buffer: a chain -- is recognised by its addresses and queues the pending
+ * seam launch first, as does one that writes another geometry into the same buffer: correct, just not folded.
+ * Same bytes either way.  Off by default; SRCNN_MODE_MFMA only (the other modes ignore it). */
 int srcnn_set_seam_deferral(srcnn_ctx *ctx, int on);
 int srcnn_flush(srcnn_ctx *ctx);
 
@@ -366,7 +370,7 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 /* SRCNN_MODE_REFBYTES: counters accumulated over the context's launches in that mode since creation (64-bit on the device).
  * out[0] = pixels flagged and recomputed one by one, out[1] = 12x12 tiles recomputed whole (flat / periodic
  * content), out[2] = bytes the recomputation changed, out[3] = fix-ups (a launch, or the <= 16 frames of a batch that share
- * one) redone in the reference's arithmetic on every pixel because their monitored deviation exceeded delta / 2;
+ * one) redone in the reference's arithmetic on every pixel because a monitored deviation exceeded half its pixel's threshold;
  * *delta = the flag threshold of the loaded model, *max_dev = the largest |v_mfma - v_reference| met on a
  * flagged pixel (a random ~0.3 % sample of all pixels).  Synchronises the stream.
  *
@@ -386,6 +390,19 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 int srcnn_fixup_stats(srcnn_ctx *ctx, unsigned long long out[4], float *delta, float *max_dev);
 int srcnn_set_fixup_strict(srcnn_ctx *ctx, int on);
 int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
+/* THE PER-PIXEL THRESHOLD (round 6, SRCNN_MODE_REFBYTES; REFBYTES16 keeps the one global threshold).  The rounding noise of a
+ * pixel scales with ITS OWN activations, so the float32 MFMA kernel flags pixel x against
+ *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs),
+ * S1(x) = the sum over the pixel's 5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c -- carried through the kernel in five
+ * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.455 (k = 1.82 with the default margin 4):
+ * 1.73 x the worst ratio an adversarial search ON THAT RATIO found (1.05, profiles/r06/fixup_adversarial_ratio.txt) -- the factor
+ * the global delta keeps over the worst deviation found -- and 3.7 x the worst ratio on content (fixup_local_scale.txt), with 0.45-0.6 x the
+ * flagged pixels on ordinary content.  The monitor and the device-side net compare each recomputed pixel's deviation with ITS
+ * threshold (rerun above 1/2).  k_local = 0: the one global threshold of rounds 3-5.
+ * srcnn_fixup_local_stats: *k = margin * k_local in effect, *max_ratio = the largest |v_mfma - v_reference| / thr(x) met on a
+ * flagged pixel since the context was created (synchronises the stream). */
+int srcnn_set_fixup_local(srcnn_ctx *ctx, float k_local);
+int srcnn_fixup_local_stats(srcnn_ctx *ctx, float *k, float *max_ratio);
 
 /* Launch geometry the fused kernel would use for (width,height,n_frames):
  * out[0]=workgroups, out[1]=rows per segment (the tallest one when a single plane is cut into

@@ -78,6 +78,9 @@ def lib() -> C.CDLL:
         _lib.srcnn_adv_point.argtypes = [_u8p, _f32p, _f32p, _f32p]
         _lib.srcnn_adv_search.argtypes = [_f32p, _u8p, i, i, i, C.c_uint64, _u8p, _f32p, _f32p]
         _lib.srcnn_adv_search.restype = C.c_long
+        _lib.srcnn_adv_point_local.argtypes = [_u8p, _f32p, _f32p, _f32p, _f32p]
+        _lib.srcnn_adv_search_ratio.argtypes = [_f32p, _u8p, i, i, C.c_float, C.c_uint64, _u8p, _f32p, _f32p]
+        _lib.srcnn_adv_search_ratio.restype = C.c_long
         # One OpenMP thread per logical CPU is the worst choice for a checker that mostly sees small planes: on the 256-thread
         # hosts of the GPU boxes (shared with other tenants) 256 threads took 0.56 s per 300x260 plane, 64 threads 0.07 s
         # (tests/checks/oracle_selfcheck.py).  Unless the caller said otherwise (OMP_NUM_THREADS, set_threads()): half the
@@ -329,3 +332,30 @@ def adv_search(starts, blob, iters, seed=1, scale_iters=0):
                                    dev.ctypes.data_as(_f32p), vals.ctypes.data_as(_f32p))
     assert evals >= 0
     return wins, dev, vals, int(evals)
+
+
+def adv_point_local(win, blob):
+    """(v_ref, v_gpu, S1) of the centre pixel of a 13 x 13 window: adv_point() plus the local scale SRCNN_MODE_REFBYTES'
+    per-pixel threshold is proportional to (oracle/adversarial.c, adv_eval_scale2)."""
+    win, pw = _u8(win)
+    assert win.shape == (13, 13)
+    blob, pb = _f32(blob)
+    a, b, s = C.c_float(), C.c_float(), C.c_float()
+    assert lib().srcnn_adv_point_local(pw, pb, C.byref(a), C.byref(b), C.byref(s)) == 0
+    return float(a.value), float(b.value), float(s.value)
+
+
+def adv_search_ratio(starts, blob, iters, abs_term, seed=1):
+    """Coordinate ascent on the factor k a per-pixel threshold k * 2^-24 * S1 + abs_term needs to cover |v_gpu - v_ref|.
+    -> (windows [n, 13, 13], ratio [n], values [n, 3] = (v_ref, v_gpu, S1), point evaluations)."""
+    starts, ps = _u8(starts)
+    n = starts.shape[0]
+    assert starts.shape[1:] == (13, 13)
+    blob, pb = _f32(blob)
+    wins = np.empty_like(starts)
+    ratio = np.empty(n, np.float32)
+    vals = np.empty((n, 3), np.float32)
+    evals = lib().srcnn_adv_search_ratio(pb, ps, n, int(iters), float(abs_term), int(seed), wins.ctypes.data_as(_u8p),
+                                         ratio.ctypes.data_as(_f32p), vals.ctypes.data_as(_f32p))
+    assert evals >= 0
+    return wins, ratio, vals, int(evals)

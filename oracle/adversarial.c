@@ -54,7 +54,7 @@ static void adv_model(const float *weights, AdvModel *m)
 
 /* The centre pixel (6, 6) of a 13 x 13 window in both arithmetics.  No border is involved: the 25 feature positions
  * (4..8, 4..8) read luma rows / columns 0..12. */
-static void adv_eval_scale(const AdvModel *m, const uint8_t *win, float *v_ref, float *v_gpu, float *scale)
+static void adv_eval_scale2(const AdvModel *m, const uint8_t *win, float *v_ref, float *v_gpu, float *scale, float *local)
 {
     float Fr[25][32], Fg[25][32];
     for (int p = 0; p < 25; p++) {
@@ -125,6 +125,24 @@ static void adv_eval_scale(const AdvModel *m, const uint8_t *win, float *v_ref, 
             for (int c = 0; c < 32; c++) sc += fabsf(m->w3t[t][c] * Fr[t][c]);
         *scale = sc;
     }
+    /* the LOCAL scale SRCNN_MODE_REFBYTES' per-pixel threshold is proportional to (round 6): S1 = the sum over the pixel's
+     * 5 x 5 feature window of U = sum_c a_c * F_c with a_c = max_tap |W3[c][tap]|, on the kernels' own layer-2 map.  (The
+     * kernels sum it in another order -- one more layer-3 accumulator row, then the vertical chains and the horizontal
+     * 5-term sum; S1 only scales a threshold, its last bits decide nothing.) */
+    if (local) {
+        float amax[32], s1 = 0.f;
+        for (int c = 0; c < 32; c++) {
+            amax[c] = 0.f;
+            for (int t = 0; t < 25; t++) amax[c] = fmaxf(amax[c], fabsf(m->w3t[t][c]));
+        }
+        for (int t = 0; t < 25; t++)
+            for (int c = 0; c < 32; c++) s1 += amax[c] * Fg[t][c];
+        *local = s1;
+    }
+}
+static void adv_eval_scale(const AdvModel *m, const uint8_t *win, float *v_ref, float *v_gpu, float *scale)
+{
+    adv_eval_scale2(m, win, v_ref, v_gpu, scale, NULL);
 }
 static void adv_eval(const AdvModel *m, const uint8_t *win, float *v_ref, float *v_gpu) { adv_eval_scale(m, win, v_ref, v_gpu, NULL); }
 
@@ -134,6 +152,16 @@ int srcnn_adv_point(const uint8_t *win /*[13][13]*/, const float *weights, float
     if (!win || !weights || !v_ref || !v_gpu) return -1;
     adv_model(weights, &m);
     adv_eval(&m, win, v_ref, v_gpu);
+    return 0;
+}
+
+/* ... and the local scale S1 of that pixel (see adv_eval_scale2) */
+int srcnn_adv_point_local(const uint8_t *win /*[13][13]*/, const float *weights, float *v_ref, float *v_gpu, float *s1)
+{
+    AdvModel m;
+    if (!win || !weights || !v_ref || !v_gpu || !s1) return -1;
+    adv_model(weights, &m);
+    adv_eval_scale2(&m, win, v_ref, v_gpu, NULL, s1);
     return 0;
 }
 
@@ -200,6 +228,53 @@ long srcnn_adv_search(const float *weights, const uint8_t *starts, int n, int it
         memcpy(out_wins + (size_t)r * WIN * WIN, w, sizeof w);
         out_dev[r] = best;
         if (out_v) { out_v[2 * r] = bvr; out_v[2 * r + 1] = bvg; }
+    }
+    return evals;
+}
+
+/* The same climb on the RATIO a per-pixel threshold  k * 2^-24 * S1 + abs_term  has to cover (round 6):
+ *   score = max(|v_gpu - v_ref| - abs_term, 0) / (2^-24 * S1)
+ * i.e. the factor k this window needs.  A window may win by a large deviation or by a small local scale -- which is what
+ * sampling |v_gpu - v_ref| alone (srcnn_adv_search) cannot show.  out_v[n][3] = (v_ref, v_gpu, S1); out_dev[n] = the ratio. */
+long srcnn_adv_search_ratio(const float *weights, const uint8_t *starts, int n, int iters, float abs_term, uint64_t seed,
+                            uint8_t *out_wins, float *out_dev, float *out_v)
+{
+    AdvModel m;
+    if (!weights || !starts || !out_wins || !out_dev || n <= 0 || iters < 0) return -1;
+    adv_model(weights, &m);
+    long evals = 0;
+    const float eps = 5.9604644775390625e-08f;      /* 2^-24 */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : evals)
+    for (int r = 0; r < n; r++) {
+        uint8_t w[WIN * WIN];
+        memcpy(w, starts + (size_t)r * WIN * WIN, sizeof w);
+        uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t)r * 0x9e3779b97f4a7c15ull + 1;
+        float vr, vg, s1;
+        adv_eval_scale2(&m, w, &vr, &vg, NULL, &s1);
+        float d = adv_score(vr, vg) - abs_term;
+        float best = (d > 0.f && s1 > 0.f) ? d / (eps * s1) : 0.f, bvr = vr, bvg = vg, bs1 = s1;
+        ++evals;
+        for (int it = 0; it < iters; it++) {
+            const uint64_t z = adv_rng(&s);
+            const int at = (int)(z % (WIN * WIN)), kind = (int)((z >> 16) & 7);
+            const uint8_t old = w[at];
+            int nv;
+            if (kind < 3) nv = (int)((z >> 24) & 255);
+            else if (kind < 6) nv = (int)old + (int)((z >> 24) % 17) - 8;
+            else nv = (z >> 24) & 1 ? 255 : 0;
+            nv = nv < 0 ? 0 : (nv > 255 ? 255 : nv);
+            if (nv == old) continue;
+            w[at] = (uint8_t)nv;
+            adv_eval_scale2(&m, w, &vr, &vg, NULL, &s1);
+            ++evals;
+            d = adv_score(vr, vg) - abs_term;
+            const float sc = (d > 0.f && s1 > 0.f) ? d / (eps * s1) : 0.f;
+            if (sc > best) { best = sc; bvr = vr; bvg = vg; bs1 = s1; }
+            else w[at] = old;
+        }
+        memcpy(out_wins + (size_t)r * WIN * WIN, w, sizeof w);
+        out_dev[r] = best;
+        if (out_v) { out_v[3 * r] = bvr; out_v[3 * r + 1] = bvg; out_v[3 * r + 2] = bs1; }
     }
     return evals;
 }

@@ -138,6 +138,8 @@ def load_library() -> C.CDLL:
         "srcnn_set_seam_deferral": ([vp, i], i),
         "srcnn_flush": ([vp], i),
         "srcnn_set_fixup_margin": ([vp, C.c_float], i),
+        "srcnn_set_fixup_local": ([vp, C.c_float], i),
+        "srcnn_fixup_local_stats": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_bgr2ycrcb": ([vp, _u8p, sz, i, i, _u8p, _u8p, _u8p, sz], i),
         "srcnn_ycrcb2bgr": ([vp, _u8p, _u8p, _u8p, sz, i, i, _u8p, sz], i),
@@ -165,7 +167,7 @@ ABI_SYMBOLS = (
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
-    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_set_seam_deferral", "srcnn_flush", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
+    "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_set_fixup_local", "srcnn_fixup_local_stats", "srcnn_set_seam_deferral", "srcnn_flush", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
     "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_frames", "srcnn_forward_y_striped_dev",
 )
@@ -352,6 +354,17 @@ class Context:
     def set_fixup_margin(self, factor: float):
         """SRCNN_MODE_REFBYTES: delta = factor x (noise scale of the model) + absolute term; default 4."""
         self._check(self._lib.srcnn_set_fixup_margin(self._h, float(factor)))
+
+    def set_fixup_local(self, k_local: float):
+        """SRCNN_MODE_REFBYTES: the per-pixel flag threshold min(delta, margin * k_local * 2^-24 * S1(x) + abs); 0 = the one
+        global threshold of rounds 3-5 (srcnn_set_fixup_local)."""
+        self._check(self._lib.srcnn_set_fixup_local(self._h, float(k_local)))
+
+    def fixup_local_stats(self):
+        """(k in effect, largest |v_mfma - v_reference| / the pixel's own threshold met so far) -- srcnn_fixup_local_stats."""
+        k, r = C.c_float(), C.c_float()
+        self._check(self._lib.srcnn_fixup_local_stats(self._h, C.byref(k), C.byref(r)))
+        return float(k.value), float(r.value)
 
     # the two reference calls with the 32-plane map kept in device memory between them (include/srcnn_amd.h)
     def dev_alloc(self, nbytes: int) -> int:

@@ -32,6 +32,9 @@ int reserve(srcnn_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return SRCNN_OK;
     if (b.p) {
+        // a deferred seam launch may still have to READ this buffer (its seam scratch, the set a non-deferring launch shares
+        // with it): queue it before the buffer goes -- the synchronize below then waits for it
+        if (int rc = flush_seams(c)) return rc;
         HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipFree(b.p));
         b.p = nullptr;
@@ -196,7 +199,7 @@ int srcnn_fixup_stats(srcnn_ctx *c, unsigned long long out[4], float *delta, flo
 {
     BIND(c);
     if (!out) return fail(c, SRCNN_ERR_INVALID, "fixup_stats: null output");
-    unsigned long long t[FIX_TOTALS] = {0, 0, 0, 0, 0};
+    unsigned long long t[FIX_TOTALS] = {0, 0, 0, 0, 0, 0};
     if (c->fix_totals.p) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipMemcpy(t, c->fix_totals.p, sizeof(t), hipMemcpyDeviceToHost));
@@ -209,6 +212,30 @@ int srcnn_fixup_stats(srcnn_ctx *c, unsigned long long out[4], float *delta, flo
     if (max_dev) {
         const unsigned bits = (unsigned)t[FIX_MAX_DEV];
         std::memcpy(max_dev, &bits, sizeof(float));
+    }
+    return SRCNN_OK;
+}
+
+int srcnn_set_fixup_local(srcnn_ctx *c, float k_local)
+{
+    BIND(c);
+    if (!(k_local >= 0.f && k_local <= 64.f)) return fail(c, SRCNN_ERR_INVALID, "set_fixup_local: the factor must lie in [0, 64]");
+    c->fix_local = k_local;
+    return SRCNN_OK;
+}
+
+int srcnn_fixup_local_stats(srcnn_ctx *c, float *k, float *max_ratio)
+{
+    BIND(c);
+    if (k) *k = c->mode == SRCNN_MODE_REFBYTES16 ? 0.f : c->fix_local * c->fix_margin;
+    if (max_ratio) {
+        unsigned long long t[FIX_TOTALS] = {0, 0, 0, 0, 0, 0};
+        if (c->fix_totals.p) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpy(t, c->fix_totals.p, sizeof(t), hipMemcpyDeviceToHost));
+        }
+        const unsigned bits = (unsigned)t[FIX_MAX_RATIO];
+        std::memcpy(max_ratio, &bits, sizeof(float));
     }
     return SRCNN_OK;
 }

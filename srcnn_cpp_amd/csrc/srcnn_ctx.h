@@ -132,6 +132,11 @@ public:
 
 // SRCNN_MODE_REFBYTES: default factor of the flag threshold's weight-proportional term (fixup_delta(), srcnn_set_fixup_margin)
 constexpr float kFixMargin = 4.f;
+// ... its absolute term (roundings at the output's own magnitude: fixup_delta()), and the factor of the PER-PIXEL threshold
+// min(delta, margin * kFixLocal * 2^-24 * S1(x) + abs) per unit of that margin (round 6; srcnn_set_fixup_local):
+// S1 = the pixel's local scale (srcnn_kernels.h, l3_row_is_scale()).  With the default margin: k = 4 * kFixLocal.
+constexpr float kFixAbsTerm = 4.f * 256.f / 16777216.f;
+constexpr float kFixLocal = 0.455f;
 
 struct srcnn_ctx {
     int device = 0;
@@ -225,6 +230,7 @@ struct srcnn_ctx {
     } pending;
     float fix_delta = 0.f;                 // SRCNN_MODE_REFBYTES: flag threshold for the uploaded model (fixup_delta())
     float fix_margin = kFixMargin;         // ... the factor of its weight-proportional term (srcnn_set_fixup_margin)
+    float fix_local = kFixLocal;           // ... the per-pixel threshold's factor per unit of the margin; 0 = the global threshold only (srcnn_set_fixup_local)
     bool fix_strict = true;                // ... act on the monitor: a launch whose max_dev > delta / 2 is redone in the reference's arithmetic (fix_rerun_kernel)
     srcnn::host::DevBuf fix_totals;                     // ... and its counters accumulated over the context's launches (srcnn_fixup_stats)
     std::unique_ptr<srcnn::host::WorkerPool> pool;      // host threads of the several-GPUs calls this context leads (WorkerPool)

@@ -46,6 +46,16 @@ __host__ __device__ constexpr int l3_row_tap(int i)
     const int r = (i & 3) + 4 * (i >> 3), h = (i >> 2) & 1, s = r / 5, m = r % 5, n = h ? 3 + s : s;
     return (r < 15 && n < 5) ? 5 * m + n : -1;
 }
+// Five of the 7 unused rows -- registers 10..14 of lane-half 1, which the vertical chains and the F tile treat as a sixth tap
+// column (plane 5) anyway -- carry the LOCAL SCALE of SRCNN_MODE_REFBYTES' per-pixel flag threshold (round 6): weight
+// a_c = max_tap |W3[c][tap]| in every one of them, so that plane 5 of a finished F-tile row holds, at no extra instruction,
+// V(y, x) = sum over the 5 feature rows y-2..y+2 of U(., x), U = sum_c a_c * F_c, and the pixel's scale is the 5-term
+// horizontal sum S1(y, x) = sum_n V(y, clamp(x + n - 2)).  Nothing else reads those rows: every output byte is as before.
+__host__ __device__ constexpr bool l3_row_is_scale(int i)
+{
+    const int r = (i & 3) + 4 * (i >> 3), h = (i >> 2) & 1;
+    return h == 1 && r >= 10 && r < 15;
+}
 
 // ---- split-f16 variant (srcnn_split16.hip): A-operand fragments of v_mfma_f32_32x32x16_f16 ----
 // [S16_NFRAG][64 lanes][8 halfs]: L1 (tile t, part s = hi|lo, k-block b) at (2t+s)*6+b, L2 (s, b) at
@@ -104,7 +114,10 @@ struct StripParams {
     int tune;                       // experiment switches (SRCNN_DEBUG_TUNE), 0 in production
     // SRCNN_MODE_REFBYTES (srcnn_exact.hip, "the reference's bytes"): a flag byte beside every output byte, same offsets as dst
     uint8_t *flag;                  // null = no flags
-    float fix_delta, fix_scale;     // flag where |v - rint(v)| <= fix_delta; code = 1 + (v - rint(v) + delta) * scale, scale = 253 / (2 delta)
+    float fix_delta, fix_scale;     // flag where |v - rint(v)| <= threshold <= fix_delta; code = 1 + (v - rint(v) + delta) * scale, scale = 253 / (2 delta)
+    // the per-pixel threshold (float32 MFMA kernel): min(fix_delta, fix_kl * S1 + fix_abs), S1 = the pixel's local scale
+    // (l3_row_is_scale()); fix_kl = 0, fix_abs = fix_delta: the one global threshold of rounds 3-5
+    float fix_kl, fix_abs;
     unsigned *fix_counters;         // FixParams::counters: the strip kernel's first block zeroes them for the launch
 };
 
@@ -114,11 +127,13 @@ struct StripParams {
 // with its own pair of reservation words: a returning atomic on ONE word sustains ~88 per microsecond chip-wide, and
 // fix_collect_kernel makes one reservation per workgroup -- 900 of them on a 3840x2160 plane (one word: 16.3 us for the kernel,
 // eight: 8.0).
-enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_N_RERUN = 4, FIX_TOTALS = 5,
+enum { FIX_N_SCAT = 0, FIX_N_DENSE = 1, FIX_N_CHANGED = 2, FIX_MAX_DEV = 3, FIX_N_RERUN = 4,
+       FIX_MAX_RATIO = 5,    // the largest |v_mfma - v_reference| / (the pixel's own threshold): what the verdict is taken from
+       FIX_TOTALS = 6,
        FIX_WORD_STRIDE = 64,
-       FIX_NEXT_ITEM = 5,    // item draw of fix_apply_kernel
-       FIX_NEXT_RERUN = 6,   // tile draw of fix_rerun_kernel
-       FIX_REGIONS = 8, FIX_REGION0 = 7 * FIX_WORD_STRIDE,      // region r: [FIX_REGION0 + r * FIX_WORD_STRIDE] scattered pixels, [+ 32] dense tiles
+       FIX_NEXT_ITEM = 6,    // item draw of fix_apply_kernel
+       FIX_NEXT_RERUN = 7,   // tile draw of fix_rerun_kernel
+       FIX_REGIONS = 8, FIX_REGION0 = 8 * FIX_WORD_STRIDE,      // region r: [FIX_REGION0 + r * FIX_WORD_STRIDE] scattered pixels, [+ 32] dense tiles
        FIX_COUNTERS = FIX_REGION0 + FIX_REGIONS * FIX_WORD_STRIDE };
 struct FixParams {
     const uint8_t *src;             // the launch's Y input, as the strip kernel reads it
@@ -137,9 +152,10 @@ struct FixParams {
     unsigned long long *totals;     // FIX_TOTALS 64-bit words, accumulated over every launch of the context (srcnn_fixup_stats)
     unsigned *scat, *dense;         // work lists in FIX_REGIONS equal regions: pixel (frame * height + y) * width + x; tile index
     float delta, code_step;         // code_step = 2 delta / 253
+    float kl, abs_term;             // the strip kernel's per-pixel threshold min(delta, kl * S1 + abs_term) (StripParams::fix_kl, fix_abs)
     // The monitor ACTS, on the device: fix_rerun_kernel, queued behind fix_apply_kernel unconditionally, compares the launch's largest
-    // |v_mfma - v_reference| with rerun_above (delta / 2; negative = always: the test hook) and recomputes every pixel of the
-    // launch in the reference's arithmetic when it is exceeded.
+    // |v_mfma - v_reference| / threshold(pixel) with rerun_above (1/2; negative = always: the test hook) and recomputes every pixel
+    // of the launch in the reference's arithmetic when it is exceeded.
     float rerun_above;
     // one fix-up for the planes of several single-frame strip launches (srcnn_forward_y_dev): frame k of the batch lies at
     // src + k * src_frame_pitch / dst + k * dst_frame_pitch / flag + k * flag_frame_pitch, same rows in every frame
@@ -148,13 +164,19 @@ struct FixParams {
 };
 // SRCNN_MODE_REFBYTES: the flag byte stored beside an output byte (srcnn_kernels.h, srcnn_exact.hip): 0, or 1 + the position of
 // v - rint(v) in [-delta, +delta] on a 253-step scale, for the values a rounding difference of the MFMA path could carry across
-// a truncation boundary: |v - rint(v)| <= delta and 0.5 < v < 255.5 (the store truncates toward zero and clamps: (-1, 1) -> 0,
+// a truncation boundary: |v - rint(v)| <= thr and 0.5 < v < 255.5 (the store truncates toward zero and clamps: (-1, 1) -> 0,
 // >= 255 -> 255, so there is no boundary at 0 nor above 255).  The range test is ONE unsigned compare on the float's bits.
-__device__ __forceinline__ uint8_t fix_code(float v, float delta, float scale)
+// thr <= delta is the pixel's own threshold (fix_threshold()); the CODE stays on the scale of the global delta, so the
+// fix-up kernels decode every pixel the same way.
+__device__ __forceinline__ float fix_threshold(float s1, float delta, float kl, float abs_term)
+{
+    return __builtin_fminf(delta, __builtin_fmaf(s1, kl, abs_term));
+}
+__device__ __forceinline__ uint8_t fix_code(float v, float thr, float delta, float scale)
 {
     // (device code only; the host translation units include this header for the parameter structs)
     const float dist = v - __builtin_rintf(v);
-    const bool live = (__builtin_fabsf(dist) <= delta) & ((__builtin_bit_cast(unsigned, v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
+    const bool live = (__builtin_fabsf(dist) <= thr) & ((__builtin_bit_cast(unsigned, v) - 0x3f000000u) < (0x437f8000u - 0x3f000000u));
     const unsigned code = (unsigned)((dist + delta) * scale + 1.5f);
     return live ? (uint8_t)code : (uint8_t)0;
 }

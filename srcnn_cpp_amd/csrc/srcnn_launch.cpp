@@ -40,10 +40,11 @@ int flush_seams(srcnn_ctx *c)
 }
 
 // May the seam blocks of the pending launch `a` run inside launch `b`'s kernel?  They write a's seam pixels while b's work items
-// write b's regular pixels: harmless when the two outputs are disjoint, and when b is the SAME launch again (same output, same
-// geometry, same work-item plan -- a step loop on one output buffer: b's own seam pixels are the ones a's blocks write, and b's
-// seam blocks rewrite them behind b).  Anything else that overlaps (another geometry into the same buffer) could let a stale
-// seam pixel of a land on a finished pixel of b: queue a's seam launch first.
+// READ b's input and write b's regular pixels.  (1) b must read nothing a's seam blocks write: a chain (b's src, or one of its halo
+// buffers, is a's output) would otherwise see a's seam pixels before they are finished.  (2) The two outputs must be disjoint, or b
+// the SAME launch again (same output, same geometry, same work-item plan -- a step loop on one output buffer: b's own seam pixels
+// are the ones a's blocks write, and b's seam blocks rewrite them behind b).  Anything else that overlaps (another geometry into
+// the same buffer) could let a stale seam pixel of a land on a finished pixel of b: queue a's seam launch first.
 static bool fold_is_safe(const StripParams &a, const StripParams &b)
 {
     auto span = [](const StripParams &q, const uint8_t **lo, size_t *bytes) {
@@ -54,6 +55,17 @@ static bool fold_is_safe(const StripParams &a, const StripParams &b)
     size_t ab, bb;
     span(a, &alo, &ab);
     span(b, &blo, &bb);
+    // the input rows b's work items read: [row_begin - 6, row_end + 6) clipped to the plane, wherever they lie (src, or a halo buffer)
+    {
+        const int r0 = std::max(0, b.row_begin - kHaloRows), r1 = std::min(b.height, b.row_end + kHaloRows);
+        const int s0 = b.src_top ? std::max(r0, b.src_row0) : r0, s1 = b.src_bot ? std::min(r1, b.src_row1) : r1;
+        if (s1 > s0 && ranges_overlap(alo, ab, b.src + (long)(s0 - b.src_row0) * b.src_stride,
+                                      (size_t)(s1 - s0 - 1) * (size_t)b.src_stride + (size_t)b.width))
+            return false;
+        const size_t halo_bytes = (size_t)(kHaloRows - 1) * (size_t)b.halo_stride + (size_t)b.width;
+        if (b.src_top && ranges_overlap(alo, ab, b.src_top, halo_bytes)) return false;
+        if (b.src_bot && ranges_overlap(alo, ab, b.src_bot, halo_bytes)) return false;
+    }
     if (!ranges_overlap(alo, ab, blo, bb)) return true;
     return a.dst == b.dst && a.dst_stride == b.dst_stride && a.dst_row0 == b.dst_row0 && a.width == b.width && a.height == b.height &&
            a.row_begin == b.row_begin && a.row_end == b.row_end && a.items == b.items && a.strips_total == b.strips_total;
@@ -250,6 +262,11 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         fix_delta_used = c->mode == SRCNN_MODE_REFBYTES16 ? c->fix_delta * (8.f / 6.f) : c->fix_delta;
         p.fix_delta = fix_delta_used;
         p.fix_scale = 253.f / (2.f * fix_delta_used);
+        // the per-pixel threshold min(delta, kl * S1 + abs) of the float32 MFMA kernel (srcnn_kernels.h, l3_row_is_scale());
+        // the split-f16 kernel carries no local scale and keeps its one global threshold, as does srcnn_set_fixup_local(ctx, 0)
+        const bool local = c->mode == SRCNN_MODE_REFBYTES && c->fix_local > 0.f;
+        p.fix_kl = local ? c->fix_local * c->fix_margin * std::ldexp(1.f, -24) : 0.f;
+        p.fix_abs = local ? kFixAbsTerm : fix_delta_used;
         p.fix_counters = static_cast<unsigned *>(fsc->fix_counters.p);
     }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
@@ -323,12 +340,14 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         f.dense = f.scat + fix_scat_cap;
         f.delta = fix_delta_used;
         f.code_step = 2.f * fix_delta_used / 253.f;
+        f.kl = p.fix_kl;
+        f.abs_term = p.fix_abs;
         // The monitor ACTS, on the device (srcnn_set_fixup_strict, on by default): fix_apply_kernel records the largest
-        // |v_mfma - v_reference| over the pixels it recomputes -- a random ~0.3 % sample of the launch -- and above half the
-        // threshold, where the margin the mode rests on is gone for this content / model, fix_rerun_kernel redoes every frame of
+        // |v_mfma - v_reference| over the pixels it recomputes -- a random ~0.1-0.3 % sample of the launch -- relative to each
+        // pixel's own threshold, and above HALF of it, where the margin the mode rests on is gone for this content / model, fix_rerun_kernel redoes every frame of
         // the fix-up batch in the reference's arithmetic (no threshold involved).  No host read: the stream is never stalled.
         static const char *env_rerun = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FORCE_RERUN");     // test knob: every launch is redone
-        f.rerun_above = (env_rerun && std::atoi(env_rerun)) ? -1.f : c->fix_strict ? 0.5f * fix_delta_used : INFINITY;
+        f.rerun_above = (env_rerun && std::atoi(env_rerun)) ? -1.f : c->fix_strict ? 0.5f : INFINITY;
         HIP_TRY(c, launch_fixup(f, c->n_cu, c->fix_strict, c->stream));
     }
     return SRCNN_OK;

@@ -432,6 +432,7 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
     // seven, which export to the seam above or see the image top, and at most one row behind the last pair, or the image's
     // bottom row) go through the general body.  Same operations in the same order on every pixel: bit-identical.
     constexpr bool FASTK = fast_kernel(MODE, PRE, DIAG);
+    static_assert(!FIX || FASTK, "the flag threshold reads plane 5 through the FAST kernels' column offsets");
     constexpr int FSLOT = 6 * FW;                 // floats per F-tile slot
     int xn[5] = {0, 0, 0, 0, 0};
     bool px_ok = false;
@@ -458,14 +459,23 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
     long o_out = (long)frame * p.dst_frame_pitch + (long)(f_lo - 3 - p.dst_row0) * p.dst_stride;
     long o_src = (long)(min(f_lo + 5, y_last) - p.src_row0) * p.src_stride;
     long o_pl = (long)frame * p.pl_frame_pitch + (long)(MODE == MODE_L3 ? min(f_lo + 1, H - 1) : f_lo) * p.pl_stride;
-    auto finalize = [&](long o, float acc, bool ok) {
+    // FIX: the pixel's LOCAL SCALE S1 = sum_n V(clamp(x + n - 2)) from plane 5 of the finished F-tile row (l3_row_is_scale(),
+    // srcnn_kernels.h) -- the columns of the 5-term horizontal sum, (5 - n) planes further on -- and its flag threshold
+    auto scale_thr = [&](const float *fr) -> float {
+        float s1 = fr[xn[0] + 5 * FW];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) s1 += fr[xn[n] + (5 - n) * FW];
+        return fix_threshold(s1, p.fix_delta, p.fix_kl, p.fix_abs);
+    };
+    auto finalize = [&](long o, float acc, bool ok, const float *fr) {
         const float v = acc + p.b3;
         // (int) truncates toward zero, then clamp: src/srcnn.cpp:238-240.  Lanes that own no output pixel are masked off.
         auto row = scalar_base(p.dst + o);
         if (ok) row[lane_off((unsigned)gx)] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (FIX) {
             auto frow = scalar_base(p.flag + o);
-            if (ok) frow[lane_off((unsigned)gx)] = fix_code(v, p.fix_delta, p.fix_scale);
+            const float thr = scale_thr(fr);
+            if (ok) frow[lane_off((unsigned)gx)] = fix_code(v, thr, p.fix_delta, p.fix_scale);
         }
         if constexpr (PRE) {
             float *prow = p.pre + o;
@@ -542,7 +552,7 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
         for (int n = 1; n < 5; ++n) acc += hv[n];
         const int y = g - 2 + slot;        // slot > 0 only at the image's last feature row
         const bool rows_ok = (y >= out_lo) && (y < out_hi) && (!FASTK || half == 0);
-        finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && rows_ok);
+        finalize(slot == 0 ? o_out : o_out + (long)slot * p.dst_stride, acc, px_ok && rows_ok, ftile(g, slot));
         if (cs_row0 && rows_ok) cseam_export(ftile(g, slot), cs_row0 + y * CSEAM_FLOATS, lane, FASTK ? cl2 : cl);
     };
     // FAST body, odd rows: output rows f - 3 (lane-half 0, F slot SLOT) and f - 4 (lane-half 1, slot SLOT + 1) together.
@@ -555,6 +565,7 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
 #pragma unroll
         for (int n = 0; n < 5; ++n) hv[n] = fr[xn[n]];
     };
+    float v2 = 0.f;                               // FIX: the pair's values between hp2_use() and hp2_flag()
     auto hp2_use = [&](int f, int slot) {
         float acc = hv[0];
 #pragma unroll
@@ -563,8 +574,12 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
         auto row = scalar_base(p.dst + (o_out - p.dst_stride));        // uniform: output row f - 4
         if (px_ok) row[lane_off(st2)] = (uint8_t)clampi((int)v, 0, 255);
         if constexpr (FIX) {
-            auto frow = scalar_base(p.flag + (o_out - p.dst_stride));
-            if (px_ok) frow[lane_off(st2)] = fix_code(v, p.fix_delta, p.fix_scale);
+            // the flag needs the pixel's local scale: its five plane-5 values are read HERE, into the registers the F values
+            // have just left, and used six k-steps further on (hp2_flag()) -- LDS latency hidden like the F values' own
+            v2 = v;
+            const float *fr = fbuf + slot * FSLOT;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) hv[n] = fr[xn[n] + (5 - n) * FW];
         }
         if (do_cs) {
             const float *tile = fbuf + slot * FSLOT;
@@ -576,6 +591,15 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
             auto dst = scalar_base(cs_row0 + (f - 4) * CSEAM_FLOATS);     // uniform: the export row of output row f - 4
             if (cl2.cnt > 0) dst[cs2] = e;
         }
+    };
+
+    auto hp2_flag = [&]() {
+        float s1 = hv[0];
+#pragma unroll
+        for (int n = 1; n < 5; ++n) s1 += hv[n];
+        const float thr = fix_threshold(s1, p.fix_delta, p.fix_kl, p.fix_abs);
+        auto frow = scalar_base(p.flag + (o_out - p.dst_stride));
+        if (px_ok) frow[lane_off(st2)] = fix_code(v2, thr, p.fix_delta, p.fix_scale);
     };
 
     // Row loop.  Iteration f computes feature row f (layers 1-3, 130 MFMA per wave) and, INSIDE that
@@ -653,6 +677,9 @@ __device__ __forceinline__ void strip_body(const StripParams &p)
                         if constexpr (FAST) {
                             if (s == 2) hp2_load(SLOT_R);
                             if (s == 8) hp2_use(f, SLOT_R);
+                            if constexpr (FIX) {
+                                if (s == 14) hp2_flag();
+                            }
                         } else {
                             if (s == 2) hp_load(g, 0);
                             if (s == 8) hp_use(g, 0);
@@ -861,7 +888,9 @@ __device__ __forceinline__ void cseam_pixels(const StripParams &p, const float *
         if (xt - 2 + k >= p.width) break;
         const float val = acc[k] + p.b3;
         p.dst[o + k] = (uint8_t)clampi((int)val, 0, 255);
-        if constexpr (FIX) p.flag[o + k] = fix_code(val, p.fix_delta, p.fix_scale);
+        // (the four pixels around a strip boundary keep the global threshold: their local scale would need the plane-5 values of
+        // both strips, which the column-seam exports do not carry -- 3 % of the pixels)
+        if constexpr (FIX) p.flag[o + k] = fix_code(val, p.fix_delta, p.fix_delta, p.fix_scale);
         if constexpr (PRE) p.pre[o + k] = val;
     }
 }
@@ -943,7 +972,13 @@ __device__ __forceinline__ void seam_block(const StripParams &p, const int *__re
         const float v = acc + p.b3;
         const long o = (long)frame * p.dst_frame_pitch + (long)(b - 2 + r - p.dst_row0) * p.dst_stride + gx;
         p.dst[o] = (uint8_t)clampi((int)v, 0, 255);
-        if constexpr (FIX) p.flag[o] = fix_code(v, p.fix_delta, p.fix_scale);
+        if constexpr (FIX) {
+            // the local scale as the strip kernel has it: plane 5 = the chains of the scale rows, replayed above like the taps'
+            float s1 = ft[r][5][xn[0]];
+#pragma unroll
+            for (int n = 1; n < 5; ++n) s1 += ft[r][5][xn[n]];
+            p.flag[o] = fix_code(v, fix_threshold(s1, p.fix_delta, p.fix_kl, p.fix_abs), p.fix_delta, p.fix_scale);
+        }
         if constexpr (PRE) p.pre[o] = v;
     }
 }

@@ -97,7 +97,11 @@ void pack_fragments(const float *w1 /*[64][81]*/, const float *b1, const float *
         for (int r = 0; r < 16; ++r) {
             const int tap = l3_row_tap(i);
             const float w = tap >= 0 ? w3[(2 * r + kk) * 25 + tap] : 0.f;
-            out[(FRAG_L3 + r) * 64 + l] = std::ldexp(w, e2);
+            // the local-scale rows of the fused kernel (l3_row_is_scale()): a_c = max over the taps of |W3[c][tap]|
+            float a = 0.f;
+            if (l3_row_is_scale(i))
+                for (int t = 0; t < 25; ++t) a = std::max(a, std::fabs(w3[(2 * r + kk) * 25 + t]));
+            out[(FRAG_L3 + r) * 64 + l] = std::ldexp(tap >= 0 ? w : a, e2);
             out[(FRAG_L3U + r) * 64 + l] = w;
         }
         for (int r = 0; r < 16; ++r) {

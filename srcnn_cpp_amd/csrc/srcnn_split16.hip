@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
             asm volatile("" : "+s"(frow));
             unsigned col = (unsigned)gx;
             asm volatile("" : "+v"(col));
-            if (ok) frow[col] = fix_code(v, p.fix_delta, p.fix_scale);
+            if (ok) frow[col] = fix_code(v, p.fix_delta, p.fix_delta, p.fix_scale);
         }
         if constexpr (PRE) {
             float *dp = ok ? p.pre + o : p.sink + 64 + lane;

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Attack on the PER-PIXEL flag threshold of SRCNN_MODE_REFBYTES (round 6; CPU only, run in the build container).
+
+Round 6 flags a pixel when |v - rint(v)| <= min(delta, k * 2^-24 * S1(x) + abs) with S1 the pixel's local scale (the sum over its
+5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c, oracle/adversarial.c).  The mode returns the reference's bytes while
+|v_gpu - v_ref| stays below that threshold on every pixel, i.e. while the RATIO
+
+    kappa(x) = max(|v_gpu - v_ref| - abs, 0) / (2^-24 * S1(x))
+
+stays below k.  tests/checks/fixup_local_scale.py SAMPLES kappa over content; this script SEARCHES for it -- coordinate ascent
+over the 169 bytes of a pixel's receptive field on kappa itself (a window may win by a large deviation or by a small local
+scale), from random, natural and extreme starts and from the windows the deviation searches of rounds 4-5 found -- for the
+shipped model and for the random model family of tests/checks/soak_models.py.
+
+Writes profiles/r06/fixup_adversarial_ratio<suffix>.txt and (no suffix) tests/golden/adversarial_windows_ratio.npz.
+usage: fixup_adversarial_ratio.py [restarts_shipped=60000] [restarts_per_random_model=3000] [n_models=24] [seed] [suffix]"""
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+import srcnn_cpp_amd as S  # noqa: E402
+from fixup_adversarial import random_model, starts  # noqa: E402
+
+ABS = 4 * 2.0 ** -24 * 256
+
+
+def attack(blob, restarts, rng, label, log, seeds=None):
+    keep_w, keep_r, keep_v, evals, t0 = [], [], [], 0, time.time()
+    for frac, iters in ((0.5, 700), (0.5, 1500)):
+        n = max(8, int(restarts * frac))
+        for c0 in range(0, n, 8192):
+            st = starts(min(8192, n - c0), rng)
+            if seeds is not None and c0 == 0:
+                st[:len(seeds)] = seeds[:len(st)]
+            wins, ratio, vals, ev = oracle.adv_search_ratio(st, blob, iters, ABS, seed=int(rng.integers(1, 2 ** 31)))
+            evals += ev
+            k = np.argsort(ratio)[-64:]
+            keep_w.append(wins[k]); keep_r.append(ratio[k]); keep_v.append(vals[k])
+    w, r, v = np.concatenate(keep_w), np.concatenate(keep_r), np.concatenate(keep_v)
+    order = np.argsort(r)[::-1]
+    w, r, v = w[order], r[order], v[order]
+    _, first = np.unique(w.reshape(len(w), -1), axis=0, return_index=True)
+    sel = np.sort(first)
+    w, r, v = w[sel], r[sel], v[sel]
+    log(f"{label:<28} worst kappa {r[0]:.3f}  (|v_gpu - v_ref| {abs(v[0, 1] - v[0, 0]):.3e} at S1 {v[0, 2]:.1f}, v_gpu {v[0, 1]:.4f}; next {r[1]:.3f}, {r[2]:.3f});"
+        f" {restarts} restarts, {evals / 1e6:.1f} M point evaluations, {time.time() - t0:.0f} s")
+    return w, r, v, evals
+
+
+def main():
+    n_ship = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+    n_rand = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    n_models = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 20261004
+    suffix = sys.argv[5] if len(sys.argv) > 5 else ""
+    out_dir = ROOT / "profiles" / "r06"
+    out_dir.mkdir(parents=True, exist_ok=True)
+    lines = []
+
+    def log(s):
+        print(s, flush=True)
+        lines.append(s)
+    log("# Adversarial search for the largest kappa = max(|v_gpu - v_ref| - abs, 0) / (2^-24 * S1) of one output pixel")
+    log("# (tests/checks/fixup_adversarial_ratio.py, oracle/adversarial.c: srcnn_adv_search_ratio): the factor k a per-pixel flag")
+    log("# threshold k * 2^-24 * S1 + abs must exceed.  CPU, both arithmetics bit-exact models.")
+    rng = np.random.default_rng(seed)
+    blob = S.load_weights()
+    old = []
+    for fn in ("adversarial_windows.npz", "adversarial_windows_gpu.npz"):
+        z = np.load(ROOT / "tests" / "golden" / fn)
+        old += [z[k] for k in z.files if z[k].dtype == np.uint8 and z[k].ndim == 3 and z[k].shape[1:] == (13, 13) and "random" not in k]
+    old = np.concatenate(old)
+    w, r, v, ev_total = attack(blob, n_ship, rng, "shipped model (convdata.h)", log, seeds=old)
+    fixture = {"shipped_windows": w[:64], "shipped_kappa": r[:64], "shipped_vals": v[:64]}
+    worst = {"shipped": float(r[0])}
+    blobs, rw, rr = [], [], []
+    for m in range(n_models):
+        mb = random_model(m)
+        w2, r2, v2, ev = attack(mb, n_rand, rng, f"random model {m}", log)
+        ev_total += ev
+        worst[f"random {m}"] = float(r2[0])
+        if m < 8:
+            blobs.append(mb); rw.append(w2[:8]); rr.append(r2[:8])
+    if blobs:
+        fixture.update(random_blobs=np.stack(blobs), random_windows=np.stack(rw), random_kappa=np.stack(rr))
+    log(f"# worst kappa: shipped {worst['shipped']:.3f}, random models {max([v for k, v in worst.items() if k != 'shipped'] or [0]):.3f};"
+        f" {ev_total / 1e6:.0f} M point evaluations in total")
+    if not suffix:
+        np.savez_compressed(ROOT / "tests" / "golden" / "adversarial_windows_ratio.npz", **fixture)
+    (out_dir / f"fixup_adversarial_ratio{suffix}.txt").write_text("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

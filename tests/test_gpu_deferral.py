@@ -223,3 +223,80 @@ def test_small_and_narrow_planes_defer_too(ctx, weights_blob, w, h):
     got = got.cpu().numpy()
     for k in range(5):
         assert np.array_equal(got[k], oracle.gpuorder_forward_y(frames[k], weights_blob)[0]), k
+
+
+def test_a_batch_behind_a_pending_plane_does_not_free_its_seam_scratch(ctx, weights_blob):
+    """a launch that does not defer shares a seam-scratch set with the pending deferred launch and may have to
+    GROW it (a 4-frame batch in one launch needs four planes' seam exports) -- the pending seam launch must be queued before the
+    buffer is freed, not read from freed memory afterwards.  Two deferred planes, then the batch, against the plain form."""
+    import torch
+    w, h = 1920, 1080
+    frames = synth_batch(w, h, 6, first_frame=21)
+    d_in = torch.from_numpy(frames).cuda()
+    want = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    for k in range(6):
+        ctx.forward_y_dev(d_in[k].data_ptr(), w, 0, want[k].data_ptr(), w, 0, w, h, 1)
+    ctx.synchronize()
+    want = want.cpu().numpy()
+    for pre in (None, torch.zeros((h, w), dtype=torch.float32, device="cuda")):
+        fresh = S.Context(0)                   # a context whose scratch has only ever held ONE plane's exports
+        fresh.set_weights_blob(weights_blob)
+        fresh.set_seam_deferral(True)
+        got = torch.zeros_like(d_in)
+        torch.cuda.synchronize()
+        for k in range(2):
+            fresh.forward_y_dev(d_in[k].data_ptr(), w, 0, got[k].data_ptr(), w, 0, w, h, 1)
+        if pre is None:
+            fresh.forward_y_dev(d_in[2].data_ptr(), w, w * h, got[2].data_ptr(), w, w * h, w, h, 4)
+        else:                                  # ... a pre-clamp request never defers either (and a taller plane needs more scratch)
+            big = torch.from_numpy(synth_luma(w, 2 * h, frame=5)).cuda()
+            big_out = torch.zeros_like(big)
+            big_pre = torch.zeros((2 * h, w), dtype=torch.float32, device="cuda")
+            fresh.forward_y_dev(big.data_ptr(), w, 0, big_out.data_ptr(), w, 0, w, 2 * h, 1, d_preclamp=big_pre.data_ptr())
+        fresh.flush()
+        fresh.synchronize()
+        got = got.cpu().numpy()
+        n_checked = 6 if pre is None else 2
+        for k in range(n_checked):
+            assert np.array_equal(got[k], want[k]), (k, pre is None)
+        fresh.close()
+
+
+def test_a_chain_reads_complete_planes(ctx, weights_blob):
+    """with deferral on, a launch whose INPUT is the pending launch's output (a two-pass chain X -> B -> C, or
+    B handed over as a halo buffer) must see B's seam pixels finished: the pending seam launch is queued first, not folded in."""
+    import torch
+    w, h = 1920, 1080
+    x = synth_luma(w, h, frame=3)
+    b_want = oracle.gpuorder_forward_y(x, weights_blob)[0]
+    c_want = oracle.gpuorder_forward_y(b_want, weights_blob)[0]
+    d_x = torch.from_numpy(x).cuda()
+    ctx.set_seam_deferral(True)
+    for _ in range(3):                         # (a race would not show every time)
+        d_b, d_c = torch.zeros_like(d_x), torch.zeros_like(d_x)
+        torch.cuda.synchronize()
+        ctx.forward_y_dev(d_x.data_ptr(), w, 0, d_b.data_ptr(), w, 0, w, h, 1)
+        ctx.forward_y_dev(d_b.data_ptr(), w, 0, d_c.data_ptr(), w, 0, w, h, 1)
+        ctx.flush()
+        ctx.synchronize()
+        assert np.array_equal(d_b.cpu().numpy(), b_want)
+        assert np.array_equal(d_c.cpu().numpy(), c_want)
+    # ... and as halo rows: the lower half of a plane whose top halo buffer is the last 6 rows of the pending launch's output
+    top_src = synth_luma(w, 546, frame=8)
+    top_out = oracle.gpuorder_forward_y(top_src, weights_blob)[0]            # 546 rows; its last 6 rows become the halo
+    lower = synth_luma(w, 540, frame=9)
+    whole = np.concatenate([top_out[-6:], lower])                             # rows 534.. of a virtual 1080-row plane
+    virt = np.concatenate([np.zeros((534, w), np.uint8), whole])
+    want = oracle.gpuorder_forward_y(virt, weights_blob)[0][540:]
+    d_top_src, d_lower = torch.from_numpy(top_src).cuda(), torch.from_numpy(lower).cuda()
+    for _ in range(3):
+        d_top_out = torch.zeros((546, w), dtype=torch.uint8, device="cuda")
+        d_out = torch.zeros((540, w), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.forward_y_dev(d_top_src.data_ptr(), w, 0, d_top_out.data_ptr(), w, 0, w, 546, 1)
+        ctx.forward_y_rows_halo_dev(d_lower.data_ptr(), w, 540, 540, d_top_out[540:].data_ptr(), 0, w,
+                                    d_out.data_ptr(), w, 540, w, 1080, 540, 1080)
+        ctx.flush()
+        ctx.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), want)

@@ -22,6 +22,25 @@ def shipped_delta(blob, margin=4.0):
     return margin * 2.0 ** -24 * np.sqrt((w3 ** 2).sum()) * m2 + 4.0 * 2.0 ** -24 * 256.0
 
 
+K_LOCAL, ABS_TERM, EPS = 4.0 * 0.455, 4.0 * 2.0 ** -24 * 256.0, 2.0 ** -24      # srcnn_ctx.h: kFixMargin * kFixLocal, kFixAbsTerm
+
+
+def local_threshold(y, blob, delta, k=K_LOCAL):
+    """The PER-PIXEL threshold of round 6 (srcnn_kernels.h fix_threshold(), l3_row_is_scale()): min(delta, k * 2^-24 * S1 + abs)
+    with S1(y, x) = the sum over the pixel's 5 x 5 feature window (replicate border) of U = sum_c max_tap|W3[c][tap]| * F_c on the
+    kernels' own layer-2 map.  (The kernels sum S1 in another order; it scales a threshold, its last bits decide nothing.)"""
+    w1, b1, w2, b2, w3, _ = oracle.split_weights(blob)
+    F = oracle.gpuorder_conv99x11(y, w1, b1, w2, b2)
+    U = np.tensordot(np.abs(w3).reshape(32, 25).max(axis=1).astype(np.float64), F.astype(np.float64), axes=(0, 0))
+    h, w = U.shape
+    S1 = np.zeros_like(U)
+    for dy in range(-2, 3):
+        ys = np.clip(np.arange(h) + dy, 0, h - 1)
+        for dx in range(-2, 3):
+            S1 += U[np.ix_(ys, np.clip(np.arange(w) + dx, 0, w - 1))]
+    return np.minimum(delta, k * EPS * S1 + ABS_TERM)
+
+
 def planes():
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:150, 0:260]
@@ -51,6 +70,24 @@ def test_flagged_pixels_are_all_that_can_differ(weights_blob, name, y):
         assert np.abs(g_pre - r_pre)[live].max() < 0.5 * delta
     if name in ("synthetic", "white noise", "bright ramp"):
         assert flagged.mean() < 0.012
+
+
+@pytest.mark.parametrize("name,y", list(planes()), ids=[n for n, _ in planes()])
+def test_locally_flagged_pixels_are_all_that_can_differ(weights_blob, name, y):
+    """Round 6: the same principle against the PER-PIXEL threshold -- fewer pixels flagged, still every byte that can differ among
+    them, and no deviation above half its own pixel's threshold (what the device-side net acts on)."""
+    delta = shipped_delta(weights_blob)
+    thr = local_threshold(y, weights_blob, delta)
+    g_out, g_pre = oracle.gpuorder_forward_y(y, weights_blob)
+    r_out, r_pre = oracle.forward_y(y, weights_blob)
+    live = (g_pre > 0.5) & (g_pre < 255.5)
+    flagged = (np.abs(g_pre - np.rint(g_pre)) <= thr) & live
+    assert np.array_equal(np.where(flagged, r_out, g_out), r_out), f"{name}: bytes differ outside the flagged set"
+    if live.any():
+        assert (np.abs(g_pre.astype(np.float64) - r_pre) / thr)[live].max() < 0.5
+    if name in ("synthetic", "white noise"):
+        glob = (np.abs(g_pre - np.rint(g_pre)) <= delta) & live
+        assert thr[live].mean() < 0.6 * delta and flagged.sum() < 0.75 * glob.sum()     # (small planes: the counts are noisy)
 
 
 def test_model_with_small_weights_and_a_large_bias():

@@ -20,6 +20,7 @@ ap.add_argument("--sizes", default="3840x2160,1920x1080,7680x4320")
 ap.add_argument("--margins", default="4,6")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--modes", default="refbytes")
+ap.add_argument("--locals", default="0.455,0", help="per-pixel threshold factors to time (srcnn_set_fixup_local; 0 = the global threshold only)")
 args = ap.parse_args()
 if args.lib:
     S.use_library(args.lib)
@@ -60,12 +61,18 @@ with S.Context(0) as ctx:
             ctx.set_mode({"refbytes": S.MODE_REFBYTES, "refbytes16": S.MODE_REFBYTES16}[mode])
             for m in (float(v) for v in args.margins.split(",")):
                 ctx.set_fixup_margin(m)
-                for strict in (True, False):
-                    ctx.set_fixup_strict(strict)
-                    before = ctx.fixup_stats()
-                    t = timed(step, args.steps)
-                    st = ctx.fixup_stats()
-                    n = (st["scattered_pixels"] - before["scattered_pixels"])
-                    print(f"{size:>10} {mode:<10} margin {m:g} strict {int(strict)}  {t:8.4f} ms  x{t / t0:.3f}  "
-                          f"(+{(t - t0) * 1e3:6.1f} us; delta {st['delta']:.3e}, max_dev {st['max_dev']:.2e}, reruns {st['exact_reruns']})")
+                for kl in ((float(v) for v in args.locals.split(",")) if mode == "refbytes" and hasattr(ctx, "set_fixup_local") else (None,)):
+                    if kl is not None:
+                        ctx.set_fixup_local(kl)
+                    for strict in (True, False):
+                        ctx.set_fixup_strict(strict)
+                        before = ctx.fixup_stats()
+                        calls = max(10, int(0.4 / 1e-3 / 4)) + 3 * args.steps
+                        t = timed(step, args.steps)
+                        st = ctx.fixup_stats()
+                        n = (st["scattered_pixels"] - before["scattered_pixels"]) / calls
+                        ratio = ctx.fixup_local_stats()[1] if kl is not None else float("nan")
+                        print(f"{size:>10} {mode:<10} margin {m:g} local {kl if kl is not None else '-'} strict {int(strict)}  {t:8.4f} ms  x{t / t0:.3f}  "
+                              f"(+{(t - t0) * 1e3:6.1f} us; {n:8.0f} px flagged per plane, delta {st['delta']:.3e}, max_dev {st['max_dev']:.2e}, "
+                              f"max ratio {ratio:.3f}, reruns {st['exact_reruns']})")
         ctx.set_mode(S.MODE_MFMA)
