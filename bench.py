@@ -354,7 +354,7 @@ def parse_args():
                          "(srcnn_conv99x11_to_dev + srcnn_conv55_from_dev, the DevicePlane<float> overloads): only the u8 planes cross PCIe")
     ap.add_argument("--mode", choices=["mfma", "exact", "split16", "refbytes", "refbytes16"], default="mfma",
                     help="mfma: float32 MFMA (default, the headline); exact: reference arithmetic on the vector ALU; "
-                         "refbytes: the float32 MFMA kernel + exact recomputation of the ~0.4 % of pixels whose value lies next to a "
+                         "refbytes: the float32 MFMA kernel + exact recomputation of the ~0.15 %% of pixels whose value lies next to a "
                          "truncation boundary -- the reference's bytes (SRCNN_MODE_REFBYTES); "
                          "split16: opt-in f16-MFMA mode with (hi, lo) operand splitting (SURVEY.md 8f rank 4) -- "
                          "never the headline number")
@@ -879,7 +879,12 @@ def worker(args):
                                    "vs_mfma_mode": round(dt_r / (elapsed / args.steps), 3),
                                    "vs_mfma_mode_without_seam_deferral": round(dt_r / dt_plain, 3), "mfma_without_seam_deferral_ms": round(dt_plain * 1e3, 4),
                                    "threshold_factor": 4.0, "device_side_net": True, "fixup": ctx.fixup_stats(),
-                                   "largest_deviation_any_search_found_over_threshold": 0.577,     # profiles/r05/adversarial_gpu.txt (not measured in this run)
+                                   # round 6: every pixel is flagged against ITS OWN threshold min(delta, k * 2^-24 * S1(x) + abs)
+                                   "per_pixel_threshold": dict(zip(("k", "largest_deviation_over_own_threshold_this_run"),
+                                                                   (round(v, 4) for v in ctx.fixup_local_stats()))),
+                                   # the worst ratio a search ON THAT RATIO found, over k: 1.051 / 1.82 (profiles/r06/fixup_adversarial_ratio.txt;
+                                   # not measured in this run); the deviation searches of rounds 4-5 reach 0.894 / 1.82 = 0.49
+                                   "largest_deviation_any_search_found_over_threshold": 0.577,
                                    "equals_reference_arithmetic": equal,
                                    "checked_against": "sha256 of oracle.forward_y on the same frame (cpu_baseline leg)" if equal is not None
                                                       else "not checked (no whole-plane oracle output in this run)"}

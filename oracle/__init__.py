@@ -79,7 +79,7 @@ def lib() -> C.CDLL:
         _lib.srcnn_adv_search.argtypes = [_f32p, _u8p, i, i, i, C.c_uint64, _u8p, _f32p, _f32p]
         _lib.srcnn_adv_search.restype = C.c_long
         _lib.srcnn_adv_point_local.argtypes = [_u8p, _f32p, _f32p, _f32p, _f32p]
-        _lib.srcnn_adv_search_ratio.argtypes = [_f32p, _u8p, i, i, C.c_float, C.c_uint64, _u8p, _f32p, _f32p]
+        _lib.srcnn_adv_search_ratio.argtypes = [_f32p, _u8p, i, i, C.c_float, C.c_float, C.c_uint64, _u8p, _f32p, _f32p]
         _lib.srcnn_adv_search_ratio.restype = C.c_long
         # One OpenMP thread per logical CPU is the worst choice for a checker that mostly sees small planes: on the 256-thread
         # hosts of the GPU boxes (shared with other tenants) 256 threads took 0.56 s per 300x260 plane, 64 threads 0.07 s
@@ -223,15 +223,18 @@ def _forward_once(fn, src, ps, blob, pw):
 def _forward(fn, src, blob):
     """A checker must not be the weak link: on the GPU boxes' shared 256-thread hosts one call in ~5,000 of the OpenMP loops
     on a SMALL plane returned a band of rows computed from wrong intermediate data (profiles/r05/soak_long.txt; cause not
-    found, never seen in the 8-CPU build container).  On hosts with more than 32 logical CPUs planes up to a megapixel are
-    therefore computed twice -- a fraction of a second -- and a third time if the two runs disagree; the majority is returned
-    and the disagreement counted in `anomalies`."""
+    found, never seen in the 8-CPU build container; the C restatement is clean under AddressSanitizer + UBSan and its two
+    runs agree under 32-fold thread oversubscription here: tests/test_sanitizers.py, tests/checks/san_oracle.c).  On hosts with
+    more than 32 logical CPUs every plane is therefore computed twice and a third time if the two runs disagree; the majority is
+    returned and the disagreement counted in `anomalies`, which tests/conftest.py prints at the end of every test run."""
     global anomalies
     src, ps = _u8(src)
     blob, pw = _f32(blob)
     assert blob.size == N_WEIGHTS
     a = _forward_once(fn, src, ps, blob, pw)
-    if src.size > (1 << 20) or (os.cpu_count() or 1) <= 32:         # (large shared hosts only: where it was seen)
+    # (large shared hosts only: where it was seen -- but there EVERY size is asked twice: the planes behind the full-size
+    # bit-identity claims as well, advisor round 5; a 33-MPix plane costs the 128-core boxes ~7 s more)
+    if (os.cpu_count() or 1) <= 32 and not os.environ.get("SRCNN_ORACLE_DOUBLE_RUN"):
         return a
     b = _forward_once(fn, src, ps, blob, pw)
     if np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]):
@@ -345,9 +348,9 @@ def adv_point_local(win, blob):
     return float(a.value), float(b.value), float(s.value)
 
 
-def adv_search_ratio(starts, blob, iters, abs_term, seed=1):
-    """Coordinate ascent on the factor k a per-pixel threshold k * 2^-24 * S1 + abs_term needs to cover |v_gpu - v_ref|.
-    -> (windows [n, 13, 13], ratio [n], values [n, 3] = (v_ref, v_gpu, S1), point evaluations)."""
+def adv_search_ratio(starts, blob, iters, abs_term, gain=1.0, seed=1):
+    """Coordinate ascent on the factor k a per-pixel threshold k * 2^-24 * S1 + abs_term needs to stay `gain` times above
+    |v_gpu - v_ref|.  -> (windows [n, 13, 13], k needed [n], values [n, 3] = (v_ref, v_gpu, S1), point evaluations)."""
     starts, ps = _u8(starts)
     n = starts.shape[0]
     assert starts.shape[1:] == (13, 13)
@@ -355,7 +358,7 @@ def adv_search_ratio(starts, blob, iters, abs_term, seed=1):
     wins = np.empty_like(starts)
     ratio = np.empty(n, np.float32)
     vals = np.empty((n, 3), np.float32)
-    evals = lib().srcnn_adv_search_ratio(pb, ps, n, int(iters), float(abs_term), int(seed), wins.ctypes.data_as(_u8p),
+    evals = lib().srcnn_adv_search_ratio(pb, ps, n, int(iters), float(abs_term), float(gain), int(seed), wins.ctypes.data_as(_u8p),
                                          ratio.ctypes.data_as(_f32p), vals.ctypes.data_as(_f32p))
     assert evals >= 0
     return wins, ratio, vals, int(evals)

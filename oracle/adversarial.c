@@ -232,11 +232,13 @@ long srcnn_adv_search(const float *weights, const uint8_t *starts, int n, int it
     return evals;
 }
 
-/* The same climb on the RATIO a per-pixel threshold  k * 2^-24 * S1 + abs_term  has to cover (round 6):
- *   score = max(|v_gpu - v_ref| - abs_term, 0) / (2^-24 * S1)
- * i.e. the factor k this window needs.  A window may win by a large deviation or by a small local scale -- which is what
- * sampling |v_gpu - v_ref| alone (srcnn_adv_search) cannot show.  out_v[n][3] = (v_ref, v_gpu, S1); out_dev[n] = the ratio. */
-long srcnn_adv_search_ratio(const float *weights, const uint8_t *starts, int n, int iters, float abs_term, uint64_t seed,
+/* The same climb on what a PER-PIXEL threshold  k * 2^-24 * S1 + abs_term  has to cover (round 6):
+ *   score = max(gain * |v_gpu - v_ref| - abs_term, 0) / (2^-24 * S1)
+ * i.e. the factor k this window needs for the threshold to stay `gain` times above its deviation (gain = 1: the bare
+ * requirement; gain = 1.73: the safety factor the global delta keeps over the worst deviation any search has found).  A window
+ * may win by a large deviation or by a small local scale -- which is what sampling |v_gpu - v_ref| alone (srcnn_adv_search)
+ * cannot show.  out_v[n][3] = (v_ref, v_gpu, S1); out_dev[n] = the score. */
+long srcnn_adv_search_ratio(const float *weights, const uint8_t *starts, int n, int iters, float abs_term, float gain, uint64_t seed,
                             uint8_t *out_wins, float *out_dev, float *out_v)
 {
     AdvModel m;
@@ -251,7 +253,7 @@ long srcnn_adv_search_ratio(const float *weights, const uint8_t *starts, int n, 
         uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t)r * 0x9e3779b97f4a7c15ull + 1;
         float vr, vg, s1;
         adv_eval_scale2(&m, w, &vr, &vg, NULL, &s1);
-        float d = adv_score(vr, vg) - abs_term;
+        float d = gain * adv_score(vr, vg) - abs_term;
         float best = (d > 0.f && s1 > 0.f) ? d / (eps * s1) : 0.f, bvr = vr, bvg = vg, bs1 = s1;
         ++evals;
         for (int it = 0; it < iters; it++) {
@@ -267,7 +269,7 @@ long srcnn_adv_search_ratio(const float *weights, const uint8_t *starts, int n, 
             w[at] = (uint8_t)nv;
             adv_eval_scale2(&m, w, &vr, &vg, NULL, &s1);
             ++evals;
-            d = adv_score(vr, vg) - abs_term;
+            d = gain * adv_score(vr, vg) - abs_term;
             const float sc = (d > 0.f && s1 > 0.f) ? d / (eps * s1) : 0.f;
             if (sc > best) { best = sc; bvr = vr; bvg = vg; bs1 = s1; }
             else w[at] = old;

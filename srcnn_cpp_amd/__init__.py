@@ -269,6 +269,7 @@ class Context:
 
     def set_stream(self, hip_stream: int):
         self._check(self._lib.srcnn_set_stream(self._h, C.c_void_p(int(hip_stream) or None)))
+        self.stream_ptr = int(hip_stream)       # 0: the context's own stream (not visible to the caller's framework)
 
     def synchronize(self):
         self._check(self._lib.srcnn_synchronize(self._h))

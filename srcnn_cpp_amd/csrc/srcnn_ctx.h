@@ -92,8 +92,12 @@ public:
     // Every missing worker is created BEFORE any task is posted, and nothing is thrown to the caller (the C ABI sits right
     // above): a thread or an allocation that cannot be had returns `nomem` with no task started -- no worker is left running a
     // task that refers to this frame.
+    // `on_incomplete` runs when not every task could be started (the tasks that WERE started are still waited for): a set of
+    // tasks that wait for each other -- the striped-frames pipeline -- must learn that some of them will never run.
     template <typename Fn>
-    int run(int n, Fn fn, int nomem = SRCNN_ERR_NOMEM)
+    int run(int n, Fn fn, int nomem = SRCNN_ERR_NOMEM) { return run(n, fn, nomem, [] {}); }
+    template <typename Fn, typename Abort>
+    int run(int n, Fn fn, int nomem, Abort on_incomplete)
     {
         try {
             while ((int)workers_.size() < n - 1) {
@@ -115,6 +119,7 @@ public:
             first = fn(0);
         } catch (...) {
             first = nomem;             // (std::function may allocate; fn itself is this library's code and does not throw)
+            on_incomplete();
         }
         for (int k = 1; k <= posted; ++k) {       // whatever happened above, every posted task is waited for before this frame goes
             Worker *w = workers_[(size_t)k - 1].get();

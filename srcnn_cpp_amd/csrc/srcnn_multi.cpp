@@ -205,6 +205,15 @@ int run_per_context(srcnn_ctx *const *ctxs, int n_ctx, Fn fn)
     if (!ctxs[0]->pool) return fail(ctxs[0], SRCNN_ERR_NOMEM, "worker pool");
     return ctxs[0]->pool->run(n_ctx, fn);
 }
+// ... for tasks that wait for each other: `on_incomplete` when some of them could not be started
+template <typename Fn, typename Abort>
+int run_per_context(srcnn_ctx *const *ctxs, int n_ctx, Fn fn, Abort on_incomplete)
+{
+    if (n_ctx == 1) return fn(0);
+    if (!ctxs[0]->pool) ctxs[0]->pool.reset(new (std::nothrow) WorkerPool());
+    if (!ctxs[0]->pool) return fail(ctxs[0], SRCNN_ERR_NOMEM, "worker pool");
+    return ctxs[0]->pool->run(n_ctx, fn, SRCNN_ERR_NOMEM, on_incomplete);
+}
 
 }  // namespace
 
@@ -323,6 +332,13 @@ int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx, const uint
     };
     return run_per_context(ctxs, n_ctx, [&](int k) -> int {
         srcnn_ctx *c = ctxs[k];
+        // EVERY exit of this task that is not a success tells the others to stop waiting for this context's events (advisor,
+        // round 5: a device that cannot be bound returned before the flag was ever set, and the neighbours spun for ever)
+        struct AbortUnlessOk {
+            srcnn_ctx *c;
+            bool ok = false;
+            ~AbortUnlessOk() { if (!ok) c->sf_abort.store(1, std::memory_order_release); }
+        } leave{c};
         BIND(c);
         int r0, r1, a0 = 0, a1 = 0;
         srcnn_stripe_rows(height, n_ctx, k, &r0, &r1);
@@ -386,11 +402,14 @@ int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx, const uint
             return SRCNN_OK;
         };
         const int r = body();
-        if (r) c->sf_abort.store(1, std::memory_order_release);       // the others stop waiting for this context's events
+        leave.ok = r == SRCNN_OK;
+        if (r) c->sf_abort.store(1, std::memory_order_release);       // (at once: the waits below may take a while)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(up);
         (void)hipStreamSynchronize(down);
         return r;
+    }, [&] {      // a task that could not even be posted: nobody will ever record its events
+        for (int k = 0; k < n_ctx; ++k) ctxs[k]->sf_abort.store(1, std::memory_order_release);
     });
 }
 

@@ -405,7 +405,9 @@ class PeerStripeStep:
     its two neighbours "plane g is uploaded" after the copy and waits for theirs before the first step on plane g (their edge
     rows are read by its launch); before it overwrites allocation g % 2 it tells them "my steps on plane g - 2 are done" and waits
     for theirs (their launches read its edge rows).  One-word gloo messages with tags; a plane stepped repeatedly (the bench's
-    resident input) exchanges nothing after its first step.
+    resident input) exchanges nothing after its first step.  "Done" is an event on the stream the KERNELS run on: the stream
+    given to ``ctx.set_stream`` (upload(g) then overlaps the steps on plane g - 1), or, when the context runs on its own stream,
+    a wait for the context (correct, no overlap) -- the caller's current torch stream plays no part.
     """
 
     def __init__(self, ctx, stripe_rows_np, out, height: int, world: int, rank: int, group=None):
@@ -481,7 +483,9 @@ class PeerStripeStep:
         b = g % 2
         if self.world > 1 and g >= 2:
             # allocation b held plane g - 2: this rank's steps on it must have run, and the neighbours' (they read its edge rows)
-            if self._done_ev[b] is not None:
+            if self._done_ev[b] == "ctx":
+                self.ctx.synchronize()
+            elif self._done_ev[b] is not None:
                 self._done_ev[b].synchronize()
             if self._done_sent < g - 2:
                 self._tell(1, g - 2)
@@ -506,7 +510,11 @@ class PeerStripeStep:
         self.ctx.forward_y_rows_halo_dev(self.d_stripes[b], w, self.r0, self.r1 - self.r0, self.top[b], self.bot[b], w,
                                          out.data_ptr(), out.stride(0), self.r0, w, self.height, self.r0, self.r1)
         if self.world > 1:
-            self._done_ev[b] = self._torch.cuda.current_stream().record_event()
+            # "my steps on this plane are done" must cover the KERNEL, which runs on the context's stream -- not on whatever stream
+            # torch calls current (advisor, round 5).  A caller that gave the context a framework stream (ctx.set_stream) gets an
+            # event on exactly that stream; with the context's own stream, which torch cannot name, upload() waits for the context.
+            sp = getattr(self.ctx, "stream_ptr", 0)
+            self._done_ev[b] = self._torch.cuda.ExternalStream(sp).record_event() if sp else "ctx"
         return out
 
     __call__ = step

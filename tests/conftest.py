@@ -28,3 +28,12 @@ def gpu_ctx(weights_blob):
     ctx.set_weights_blob(weights_blob)
     yield ctx
     ctx.close()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The checker reports on itself: how often two runs of the same oracle call disagreed in this process (oracle/__init__.py
+    `_forward`: majority of three; met twice in ~11,000 planes on the shared 256-thread hosts of the GPU boxes, never at 64 threads)."""
+    mod = sys.modules.get("oracle")
+    n = getattr(mod, "anomalies", 0) if mod else 0
+    if n:
+        terminalreporter.write_line(f"ORACLE ANOMALIES: {n} oracle call(s) needed a third run to settle a disagreement between two runs", yellow=True)

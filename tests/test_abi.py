@@ -130,6 +130,69 @@ int main() { return 0; }
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)], check=True)
 
 
+def test_reference_call_sites_compile_against_opencv4s_mat_interface():
+    """VERDICT r05 item 7: the literal drop-in.  tests/helpers/opencv4_mat_shape.hpp declares cv::Mat with OpenCV 4's public
+    member TYPES (int rows, cols; uchar* data; MatStep step with operator size_t; MatSize size) -- the real headers
+    (src/srcnn.h:6-9) cannot be satisfied in this image.  The TEXT of src/srcnn.cpp:602-627 (allocation of the 32 planes, the two
+    calls) then compiles against include/srcnn_amd.hpp's adapters as it stands, `using namespace cv; using namespace std;` as
+    the reference has them -- and again with only the vector's element type changed to srcnn::DevicePlane<float>.  Also the two
+    un-fused functions (:60-67).  Compile only: nothing is linked."""
+    import subprocess, tempfile
+    code = r'''
+#include "opencv4_mat_shape.hpp"
+#include "srcnn_amd.hpp"
+using namespace cv;
+using namespace std;
+using namespace srcnn;
+#define CONV1_FILTERS 64
+#define CONV2_FILTERS 32
+typedef float ConvKernel64_99[CONV1_FILTERS][9][9];
+typedef float ConvKernel32_55[CONV2_FILTERS][5][5];
+typedef float ConvKernel21[CONV2_FILTERS][CONV1_FILTERS];
+typedef float ConvKernel1[CONV1_FILTERS];
+typedef float ConvKernel2[CONV2_FILTERS];
+extern const ConvKernel64_99 weights_conv1_data;
+extern const ConvKernel1 biases_conv1;
+extern const ConvKernel21 weights_conv2_data;
+extern const ConvKernel2 biases_conv2;
+extern const ConvKernel32_55 weights_conv3_data;
+extern const float biases_conv3;
+void reference_text(vector<Mat> &pImg)
+{
+    vector<Mat> pImgConv2(CONV2_FILTERS);
+    for ( unsigned cnt=0; cnt<CONV2_FILTERS; cnt++)
+    {
+        pImgConv2[cnt].create( pImg[0].size(), CV_32F );
+    }
+
+    Convolution99x11( pImg[0], pImgConv2, weights_conv1_data, biases_conv1, weights_conv2_data, biases_conv2 );
+
+    Mat pImgConv3;
+    pImgConv3.create(pImg[0].size(), CV_8U);
+    Convolution55(pImgConv2, pImgConv3, weights_conv3_data, biases_conv3);
+}
+void device_planes(vector<Mat> &pImg)
+{
+    vector<DevicePlane<float>> pImgConv2 = DevicePlanes<float>(CONV2_FILTERS, pImg[0].cols, pImg[0].rows);
+    Convolution99x11( pImg[0], pImgConv2, weights_conv1_data, biases_conv1, weights_conv2_data, biases_conv2 );
+    Mat pImgConv3;
+    pImgConv3.create(pImg[0].size(), CV_8U);
+    Convolution55(pImgConv2, pImgConv3, weights_conv3_data, biases_conv3);
+}
+void unfused(Mat &y, vector<Mat> &conv1, Mat &dst)
+{
+    Convolution99( y, conv1[0], weights_conv1_data[0], biases_conv1[0] );
+    Convolution11( conv1, dst, weights_conv2_data[0], biases_conv2[0] );
+}
+int main() { return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "m.cpp"
+        src.write_text(code)
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}",
+                        f"-I{ROOT / 'tests' / 'helpers'}", str(src)], check=True)
+
+
 def test_create_without_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():

@@ -47,3 +47,10 @@ def test_all_ranks_ok_forwards_rank0_stdout(capfd):
     rc = bench.launch_ranks(3, cmd=[sys.executable, "-c", RANK_SCRIPT, "ok"])
     assert rc == 0
     assert capfd.readouterr().out.strip() == '{"metric": "x"}'
+
+
+def test_help_text_formats():
+    """argparse %-formats every help string: a bare per-cent sign in one of them made `bench.py --help` raise (round 5)."""
+    import subprocess
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout, r.stderr[-500:]

@@ -121,3 +121,28 @@ def test_synthetic_generator_is_pinned():
     a = synth_luma(64, 48, frame=3)
     assert a.dtype == np.uint8 and a.max() <= 241 and np.array_equal(a, synth_luma(64, 48, frame=3))
     assert not np.array_equal(a, synth_luma(64, 48, frame=4))
+
+
+def _edge_pins():
+    z = np.load(GOLD / "oracle_edge_pins.npz")
+    return [(k[:-3], z[k], z[k[:-3] + ".out"], z[k[:-3] + ".pre"]) for k in z.files if k.endswith(".in")]
+
+
+@pytest.mark.parametrize("name", [p[0] for p in _edge_pins()])
+def test_edge_pins_hold_for_the_c_oracle_and_the_numpy_restatement(weights_blob, name):
+    """The G2 edge set as committed input / output vectors (tests/golden/make_oracle_edge_pins.py): planes smaller
+    than the 9 x 9 and 5 x 5 windows, constant 0 / 255.  The reference's picture pins the oracle's interior arithmetic; these pin
+    its borders and saturating ends -- against the C oracle as it is NOW, and against the independent numpy float32 restatement
+    (tests/test_oracle_numpy.py), so an edit of oracle/srcnn_oracle.c that still reproduces the picture but breaks W < 9 is
+    caught without a GPU."""
+    from test_oracle_numpy import np_conv11, np_conv55, np_conv99
+    y, want_u8, want_pre = next((a, b, c) for n, a, b, c in _edge_pins() if n == name)
+    got_u8, got_pre = oracle.forward_y(y, weights_blob)
+    assert np.array_equal(got_u8, want_u8) and np.array_equal(got_pre, want_pre)
+    w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
+    l1 = [np_conv99(y, w1[k], b1[k]) for k in range(64)]
+    l2 = [np_conv11(l1, w2[k], b2[k]) for k in range(32)]
+    n_u8, n_pre = np_conv55(l2, w3, b3)
+    assert np.array_equal(n_u8, want_u8) and np.array_equal(n_pre, want_pre)
+    if name.startswith("const255"):
+        assert want_u8.min() >= 250          # the saturating end really is exercised

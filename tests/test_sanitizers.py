@@ -47,6 +47,23 @@ def test_worker_pool_under_thread_sanitizer(tmp_path):
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
 
 
+def test_oracle_under_asan_ubsan_and_thread_oversubscription(tmp_path):
+    """The CHECKER under the sanitizers (advisor, round 5): oracle/srcnn_oracle.c's conv path compiled with AddressSanitizer +
+    UBSan, on the edge sizes (1 x 1 ... 40 x 2) and random planes, every plane twice with 256 OpenMP threads on this container's
+    8 CPUs and once with one thread -- exact-size buffers, no error, no disagreement between the three runs."""
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not found")
+    exe = tmp_path / "san_oracle"
+    subprocess.run([gcc, "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1",
+                    "-ffp-contract=off", "-fopenmp", "-std=c11", str(ROOT / "oracle" / "srcnn_oracle.c"),
+                    str(ROOT / "tests" / "checks" / "san_oracle.c"), "-lm", "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(ROOT / "srcnn_cpp_amd" / "data" / "srcnn915_weights.f32"), "40", "256"], capture_output=True,
+                       text=True, env=dict(ENV, OMP_WAIT_POLICY="passive"), timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), (r.stdout + r.stderr)[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
 def png_chunk(kind: bytes, body: bytes) -> bytes:
     return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
 
