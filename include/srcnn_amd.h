@@ -390,17 +390,19 @@ int srcnn_process_bgr_dev(srcnn_ctx *ctx, const uint8_t *d_bgr, size_t stride, i
 int srcnn_fixup_stats(srcnn_ctx *ctx, unsigned long long out[4], float *delta, float *max_dev);
 int srcnn_set_fixup_strict(srcnn_ctx *ctx, int on);
 int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
-/* THE PER-PIXEL THRESHOLD (round 6, SRCNN_MODE_REFBYTES; REFBYTES16 keeps the one global threshold).  The rounding noise of a
- * pixel scales with ITS OWN activations, so the float32 MFMA kernel flags pixel x against
- *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs),
- * S1(x) = the sum over the pixel's 5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c -- carried through the kernel in five
- * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.455 (k = 1.82 with the default margin 4):
- * 1.73 x the worst ratio an adversarial search ON THAT RATIO found (1.05, profiles/r06/fixup_adversarial_ratio.txt) -- the factor
- * the global delta keeps over the worst deviation found -- and 3.7 x the worst ratio on content (fixup_local_scale.txt), with 0.45-0.6 x the
- * flagged pixels on ordinary content.  The monitor and the device-side net compare each recomputed pixel's deviation with ITS
- * threshold (rerun above 1/2).  k_local = 0: the one global threshold of rounds 3-5.
- * srcnn_fixup_local_stats: *k = margin * k_local in effect, *max_ratio = the largest |v_mfma - v_reference| / thr(x) met on a
- * flagged pixel since the context was created (synchronises the stream). */
+/* THE PER-PIXEL THRESHOLD (round 6; both byte-exact modes).  The rounding noise of a pixel scales with ITS OWN activations, so
+ * the strip kernels flag pixel x against
+ *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs_local),        abs_local = 8 * 2^-24 * 256 = 1.22e-4,
+ * S1(x) = the sum over the pixel's 5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c -- carried through the kernels in five
+ * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.45 (k = 1.8 with the default margin 4;
+ * REFBYTES16: 8/6 of it, the ratio of the two modes' global thresholds): thr stays 1.73 x above the deviation of EVERY window the
+ * adversarial searches have produced -- searches on exactly that quantity included (profiles/r06/fixup_adversarial_ratio.txt,
+ * adversarial_gpu_ratio.txt) -- which is the factor the global delta keeps over the worst of them; content stays below 0.37 thr
+ * (fixup_local_scale.txt).  0.54-0.63 x the flagged pixels on ordinary content (0.24 x on sparse, 0.99 x on very bright content).
+ * The monitor and the device-side net compare each recomputed pixel's deviation with ITS threshold (rerun above 1/2).
+ * k_local = 0: the one global threshold of rounds 3-5.
+ * srcnn_fixup_local_stats: *k = margin * k_local in effect for the context's mode, *max_ratio = the largest
+ * |v_kernel - v_reference| / thr(x) met on a flagged pixel since the context was created (synchronises the stream). */
 int srcnn_set_fixup_local(srcnn_ctx *ctx, float k_local);
 int srcnn_fixup_local_stats(srcnn_ctx *ctx, float *k, float *max_ratio);
 

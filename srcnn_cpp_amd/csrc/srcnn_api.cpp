@@ -220,14 +220,16 @@ int srcnn_set_fixup_local(srcnn_ctx *c, float k_local)
 {
     BIND(c);
     if (!(k_local >= 0.f && k_local <= 64.f)) return fail(c, SRCNN_ERR_INVALID, "set_fixup_local: the factor must lie in [0, 64]");
+    // one knob for both byte-exact modes: REFBYTES16 keeps its factor 8/6 over REFBYTES (the ratio of their global thresholds)
     c->fix_local = k_local;
+    c->fix_local16 = k_local * (kFixLocal16 / kFixLocal);
     return SRCNN_OK;
 }
 
 int srcnn_fixup_local_stats(srcnn_ctx *c, float *k, float *max_ratio)
 {
     BIND(c);
-    if (k) *k = c->mode == SRCNN_MODE_REFBYTES16 ? 0.f : c->fix_local * c->fix_margin;
+    if (k) *k = (c->mode == SRCNN_MODE_REFBYTES16 ? c->fix_local16 : c->fix_local) * c->fix_margin;
     if (max_ratio) {
         unsigned long long t[FIX_TOTALS] = {0, 0, 0, 0, 0, 0};
         if (c->fix_totals.p) {

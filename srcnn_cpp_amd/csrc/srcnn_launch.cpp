@@ -71,6 +71,10 @@ static bool fold_is_safe(const StripParams &a, const StripParams &b)
            a.row_begin == b.row_begin && a.row_end == b.row_end && a.items == b.items && a.strips_total == b.strips_total;
 }
 
+// FixParams::kl from StripParams::fix_kl: the split-f16 kernel's factor carries the 2^-10 of its scaled plane 5, the fix-up kernels'
+// S1 is in true units
+static float r16_kl(const srcnn_ctx *c, float strip_kl) { return c->mode == SRCNN_MODE_REFBYTES16 ? strip_kl * 1024.f : strip_kl; }
+
 // Common launch of the three strip modes on device memory.
 // fix_frame / fix_frames (SRCNN_MODE_REFBYTES only): this single-frame launch is frame `fix_frame` of a batch of `fix_frames`
 // whose flagged pixels ONE fix-up finishes, queued behind the batch's last launch (fix_frames = 1: the launch's own fix-up).
@@ -262,11 +266,13 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         fix_delta_used = c->mode == SRCNN_MODE_REFBYTES16 ? c->fix_delta * (8.f / 6.f) : c->fix_delta;
         p.fix_delta = fix_delta_used;
         p.fix_scale = 253.f / (2.f * fix_delta_used);
-        // the per-pixel threshold min(delta, kl * S1 + abs) of the float32 MFMA kernel (srcnn_kernels.h, l3_row_is_scale());
-        // the split-f16 kernel carries no local scale and keeps its one global threshold, as does srcnn_set_fixup_local(ctx, 0)
-        const bool local = c->mode == SRCNN_MODE_REFBYTES && c->fix_local > 0.f;
-        p.fix_kl = local ? c->fix_local * c->fix_margin * std::ldexp(1.f, -24) : 0.f;
-        p.fix_abs = local ? kFixAbsTerm : fix_delta_used;
+        // the per-pixel threshold min(delta, kl * S1 + abs) of both strip kernels (srcnn_kernels.h, l3_row_is_scale());
+        // srcnn_set_fixup_local(ctx, 0): the one global threshold of rounds 3-5
+        const bool r16 = c->mode == SRCNN_MODE_REFBYTES16;
+        const bool local = (r16 ? c->fix_local16 : c->fix_local) > 0.f;
+        // (the split-f16 kernel's plane 5 is x 2^10 like its tap partials: the factor carries the 2^-10)
+        p.fix_kl = local ? (r16 ? c->fix_local16 * std::ldexp(1.f, -10) : c->fix_local) * c->fix_margin * std::ldexp(1.f, -24) : 0.f;
+        p.fix_abs = local ? kFixAbsLocal : fix_delta_used;
         p.fix_counters = static_cast<unsigned *>(fsc->fix_counters.p);
     }
     p.wfrag = static_cast<const float *>(c->wfrag.p);
@@ -340,7 +346,7 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         f.dense = f.scat + fix_scat_cap;
         f.delta = fix_delta_used;
         f.code_step = 2.f * fix_delta_used / 253.f;
-        f.kl = p.fix_kl;
+        f.kl = r16_kl(c, p.fix_kl);          // the fix-up's monitor computes S1 in true units
         f.abs_term = p.fix_abs;
         // The monitor ACTS, on the device (srcnn_set_fixup_strict, on by default): fix_apply_kernel records the largest
         // |v_mfma - v_reference| over the pixels it recomputes -- a random ~0.1-0.3 % sample of the launch -- relative to each

@@ -147,7 +147,10 @@ void pack_fragments16(const float *w1 /*[64][81]*/, const float *b1, const float
             // layer 3, k-block b: slot 8h+e is layer-2 channel acc_row(8b+e, h); row m = tap l3_row_tap(m)
             for (int b = 0; b < 2; ++b) {
                 const int c2 = acc_row(8 * b + e, h), tap = l3_row_tap(m);
-                split16(tap >= 0 ? w3[c2 * 25 + tap] : 0.f, SCALE, slot(S16_FRAG_L3 + b, l, e),
+                float a = 0.f;          // the local-scale rows (l3_row_is_scale()): a_c = max over the taps of |W3[c][tap]|, <= the f16 range the taps fit
+                if (l3_row_is_scale(m))
+                    for (int t = 0; t < 25; ++t) a = std::max(a, std::fabs(w3[c2 * 25 + t]));
+                split16(tap >= 0 ? w3[c2 * 25 + tap] : a, SCALE, slot(S16_FRAG_L3 + b, l, e),
                         slot(S16_FRAG_L3 + 2 + b, l, e));
             }
         }

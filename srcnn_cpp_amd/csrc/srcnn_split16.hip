@@ -208,6 +208,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
     for (int n = 0; n < 5; ++n) xn[n] = clampi16(clampi16(gx + n - 2, 0, W - 1) - gx0, 0, FW - 1);
     const bool px_ok = (xi >= HALO) && (xi < FW - HALO) && (gx < W);
     float R[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float hs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // FIX: plane 5 of the finished F-tile row at the pixel's five columns (the local scale)
     auto finalize = [&](int y, float acc, bool ok) {
         const float v = __builtin_fmaf(acc, S16_UNSCALE_L3, p.b3);
         const long o = (long)frame * p.dst_frame_pitch + (long)(y - p.dst_row0) * p.dst_stride + gx;
@@ -221,7 +222,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
             asm volatile("" : "+s"(frow));
             unsigned col = (unsigned)gx;
             asm volatile("" : "+v"(col));
-            if (ok) frow[col] = fix_code(v, p.fix_delta, p.fix_delta, p.fix_scale);
+            // the pixel's own threshold (srcnn_kernels.h, l3_row_is_scale()): the scale rows of the layer-3 fragments come out of the
+            // same MFMAs as the taps, x 2^10 like them (fix_kl carries the 2^-10: run_strip())
+            const float s1 = (((hs[0] + hs[1]) + hs[2]) + hs[3]) + hs[4];
+            if (ok) frow[col] = fix_code(v, fix_threshold(s1, p.fix_delta, p.fix_kl, p.fix_abs), p.fix_delta, p.fix_scale);
         }
         if constexpr (PRE) {
             float *dp = ok ? p.pre + o : p.sink + 64 + lane;
@@ -261,6 +265,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void srcnn_split16_kernel(const StripP
         const float *fr = ftile(g, slot);
 #pragma unroll
         for (int n = 0; n < 5; ++n) hv[n] = fr[n * FW + xn[n]];
+        if constexpr (FIX) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) hs[n] = fr[5 * FW + xn[n]];
+        }
     };
     auto hp_use = [&](int g, int slot, bool on) {
         float acc = hv[0];

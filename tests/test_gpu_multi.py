@@ -297,6 +297,40 @@ def test_bench_under_torch_distributed_run():
     assert st["forms"]["peer"].get("sha256_equals_golden") is True, st["forms"]["peer"]
 
 
+def test_bench_eight_ranks_under_torch_distributed_run():
+    """the driver's N = 8 command line AS IT IS -- torch.distributed.run, 8 ranks, default sizes: the frames
+    workload on 3840x2160 planes (`value`) and, in the same line, the 7680x4320 plane of configs[3] in ITS partition, 8 stripes of
+    540 rows, through both process-per-GPU transports.  The ranks share the box's one GPU, so RCCL cannot form the group (it
+    refuses duplicate devices: the line must SAY so -- `rccl_world` null, `degraded`, the halo rows staged through the host) and
+    no xGMI link is crossed; everything else of an 8-GPU run is exercised: the launcher's environment, the gloo control plane
+    with 8 members, the common start instant, the gathers, the IPC mapping of both neighbours' stripes on interior ranks, the
+    stitched plane's sha256 against the committed checksum."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--shared-gpu", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and len(d["per_rank_ms_per_step"]) == 8
+    assert d["config"]["width"] == 3840 and len(d["config"]["output_crc32"]) == 8
+    one = run_bench("--gpus", 1, "--frames", 8)
+    assert d["config"]["output_crc32"] == one["config"]["output_crc32"]          # rank k computed frame k of the stream
+    st = d["stripe"]
+    gold = json.loads((ROOT / "tests" / "golden" / "config_checksums.json").read_text())["c3_7680x4320"]["gpuorder_sha256"][0]
+    assert st["golden_sha256"] == gold
+    for form in ("halo", "peer"):
+        f = st["forms"][form]
+        assert f["output_sha256"] == gold and f["sha256_equals_golden"] is True, (form, f)
+        assert len(f["per_rank_ms"]) == 8 and f["ms_per_image"] > 0
+    assert st["forms"]["halo"]["rccl_world"] is None and st["forms"]["halo"]["halo_transport"].startswith("host-staged")
+    assert st["degraded"] is True and any("shared" in w for w in st["degraded_why"])
+
+
 def test_bench_frames_line_carries_the_striped_plane():
     """ONE driver command per N must yield both halves of the metric.  `bench.py --gpus N` (frames, weak
     scaling: `value`) now also row-stripes the 7680x4320 plane of BASELINE configs[3] over its N ranks after the timed region

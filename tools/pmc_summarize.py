@@ -155,6 +155,75 @@ if unf:
         json.dump(rec, fh, indent=1)
     print("unfused", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in rec.items()}))
 
+# ---- the kernels beside the headline strip kernel: the REFBYTES fix-up, Convolution55 alone, the pipeline
+# byte kernels -- counters per dispatch and what follows from them, one file per run:
+#   refbytes_4k_pmc_summary.json   (pmc_refbytes_*: bench.py --mode refbytes)     fix_apply_kernel, fix_collect_kernel, fix_rerun_kernel,
+#                                                                                 the flag-writing strip kernel and its seam launch
+#   pipeline_pmc_summary.json      (pmc_pipeline_*: bench.py --path pipeline)     bgr_to_y_resized_kernel, resize_merge_kernel
+#   l3_4k_pmc_summary.json         (pmc_unfused_*)                                Convolution55 alone: TB/s FROM THE COUNTERS
+def kernel_table(run, patterns, trace_tag):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(out, f"pmc_{run}_*", "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                for tag, pat in patterns:
+                    if pat in row["Kernel_Name"]:
+                        acc[tag][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                        break
+    avg_ns = {}
+    for f in glob.glob(os.path.join(out, f"trace_{trace_tag}", "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in list(csv.reader(fh))[1:]:
+                for tag, pat in patterns:
+                    if pat in r[0]:
+                        avg_ns.setdefault(tag, float(r[3]))
+                        break
+    rec = {}
+    for tag, ctrs in acc.items():
+        m = {k: sum(v) / len(v) for k, v in ctrs.items()}
+        d = {"counters_mean_per_dispatch": m, "rocprof_kernel_trace_avg_ns": avg_ns.get(tag)}
+        if "FETCH_SIZE" in m: d["hbm_read_bytes"] = m["FETCH_SIZE"] * 2048          # x2: pmc_calibration.txt
+        if "WRITE_SIZE" in m: d["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
+        if avg_ns.get(tag) and ("hbm_read_bytes" in d or "hbm_write_bytes" in d):
+            d["hbm_TB_per_s_from_counters"] = (d.get("hbm_read_bytes", 0) + d.get("hbm_write_bytes", 0)) / avg_ns[tag] / 1e3
+        if "GRBM_GUI_ACTIVE" in m and m.get("SQ_INSTS_VALU", 0) > 0:
+            simd_cycles = m["GRBM_GUI_ACTIVE"] / 8 * 1024                            # 1,024 SIMDs x the kernel's cycles
+            d["simd_cycles_per_valu_instruction"] = simd_cycles / m["SQ_INSTS_VALU"]  # 4 = one wave's issue rate; packed f32: 4.6-4.8 in the issue probe
+            if avg_ns.get(tag):
+                d["effective_clock_GHz"] = m["GRBM_GUI_ACTIVE"] / 8 / avg_ns[tag]
+        if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"] > 0:
+            for k2, name in (("SQ_ACTIVE_INST_VALU", "valu_issue_frac_of_wave_cycles"), ("SQ_ACTIVE_INST_LDS", "lds_issue_frac_of_wave_cycles"),
+                             ("SQ_ACTIVE_INST_ANY", "any_issue_frac_of_wave_cycles"), ("SQ_WAIT_INST_ANY", "issue_stall_frac_of_wave_cycles"),
+                             ("SQ_WAIT_ANY", "parked_frac_of_wave_cycles")):
+                if k2 in m: d[name] = m[k2] / m["SQ_WAVE_CYCLES"]
+        if m.get("SQ_LDS_IDX_ACTIVE", 0) > 0 and "SQ_LDS_BANK_CONFLICT" in m:
+            d["lds_bank_conflict_frac"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+        rec[tag] = d
+    return rec
+
+
+rb = kernel_table("refbytes", [("fix_apply", "fix_apply_kernel"), ("fix_collect", "fix_collect_kernel"), ("fix_rerun", "fix_rerun_kernel"),
+                               ("strip_with_flags", "srcnn_strip_kernel<0"), ("seams_with_flags", "srcnn_seams_merged_kernel")], "refbytes")
+if rb:
+    if "fix_apply" in rb and rb["fix_apply"]["counters_mean_per_dispatch"].get("SQ_INSTS_VALU"):
+        rb["fix_apply"]["note"] = ("the fix-up is vector-ALU work in the reference's arithmetic (no FMA): simd_cycles_per_valu_instruction against "
+                                   "the 4-cycle issue rate of one wave's stream says how close the kernel runs to the instruction-issue bound")
+    with open(os.path.join(out, "refbytes_4k_pmc_summary.json"), "w") as fh:
+        json.dump(rb, fh, indent=1)
+    print("refbytes", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in rb.items()}))
+pl = kernel_table("pipeline", [("bgr_to_y_resized", "bgr_to_y_resized_kernel"), ("resize_merge", "resize_merge_kernel")], "pipeline")
+if pl:
+    with open(os.path.join(out, "pipeline_pmc_summary.json"), "w") as fh:
+        json.dump(pl, fh, indent=1)
+    print("pipeline", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in pl.items()}))
+l3 = kernel_table("unfused", [("conv55_L3", "srcnn_strip_kernel<2"), ("conv99x11_L12", "srcnn_strip_kernel<1")], "unfused1")
+if l3:
+    if "conv55_L3" in l3 and "hbm_TB_per_s_from_counters" in l3["conv55_L3"]:
+        l3["conv55_L3"]["algorithmic_TB_per_s"] = 129 * 3840 * 2160 / l3["conv55_L3"]["rocprof_kernel_trace_avg_ns"] / 1e3
+    with open(os.path.join(out, "l3_4k_pmc_summary.json"), "w") as fh:
+        json.dump(l3, fh, indent=1)
+    print("l3", json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters_mean_per_dispatch"} for k, v in l3.items()}))
+
 traffic_rec["_note"] = ("per step (one 3840x2160 plane): HBM bytes of the strip kernel plus, in the float32 mode, the seam blocks (with seam deferral they run inside srcnn_strip_fold_kernel, whose counters are the step's); "
                         "FETCH_SIZE x2 (every read width is reported at half its size: profiles/r02/pmc_calibration.txt) + WRITE_SIZE, KB -> bytes; "
                         "separate --pmc passes (tools/profile_round.sh); *_mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) of the strip kernel")

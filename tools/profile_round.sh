@@ -34,6 +34,23 @@ for mode in mfma split16; do
         python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/pmc_${mode}_$tag.log 2>&1
   done
 done
+# the kernels beside the headline: the REFBYTES step (flag-writing strip kernel, fix_collect, fix_apply, idle
+# fix_rerun) and the two pipeline byte kernels -- HBM bytes, instruction mix, issue / stall split, LDS conflicts
+for run in "refbytes --mode refbytes" "pipeline --path pipeline"; do
+  set -- $run; tag=$1; shift
+  for grp in "FETCH_SIZE" "WRITE_SIZE" \
+             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+    g=$(echo $grp | cut -d' ' -f1)
+    ( cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pmc_${tag}_$g -o pmc -- \
+        python3 $ROOT/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/pmc_${tag}_$g.log 2>&1
+  done
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$tag -o trace -- \
+      python3 $ROOT/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/trace_$tag.log 2>&1
+done
+# ... and a kernel trace of ONE unfused 3840x2160 frame, the run the pmc_unfused_* passes below count (TB/s from the counters)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_unfused1 -o trace -- \
+    python3 $ROOT/bench.py --path unfused --steps 20 --warmup 3 --no-cpu-baseline ) > $OUT/trace_unfused1.log 2>&1
 if [ -z "$PMC_ONLY" ]; then
 # Convolution99x11 (<1>) and Convolution55 (<2>) alone: HBM bytes (FETCH_SIZE x2, WRITE_SIZE: pmc_calibration.txt) and instruction mix
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
