@@ -391,6 +391,8 @@ def parse_args():
                     help="N > 1, frames workload: skip the row-striped 7680x4320 plane (configs[3], ms per image) that rides on the line as `stripe`")
     ap.add_argument("--stripe-timeout-s", type=float, default=240.0,
                     help="N > 1: seconds the row-striped leg behind the frames figure may take before its watchdog prints the line without it (0 = no watchdog)")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the two-lane figure (`two_lanes`: the planes of a stream alternately on two "
+                                                            "contexts of the one GPU)")
     ap.add_argument("--no-refbytes", action="store_true", help="skip the SRCNN_MODE_REFBYTES figure and its check against the oracle's bytes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -817,6 +819,49 @@ def worker(args):
                                     "what": f"the same step back to back for {args.sustained_s:g} s in chunks of {chunk}, HIP events per chunk; never `value`"}
             except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
                 out["sustained"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        if world == 1 and args.path == "fused" and args.mode == "mfma" and not stripe and F == 1 and not args.no_lanes:
+            ctx2 = None
+            try:
+                # TWO LANES (round 6), never `value`: the planes of a stream alternately on two contexts / HIP streams of this ONE GPU
+                # (srcnn_forward_y_lanes_dev) -- the next plane's kernel fills the compute units that the previous plane's slowest
+                # workgroups leave idle.  Nothing to gain at 3840x2160 (a 2 % tail), a quarter of the step at 576x576.
+                ctx2 = S.Context(local_rank)
+                ctx2.set_weights_blob(S.load_weights())
+                stream2 = torch.cuda.Stream()
+                ctx2.set_stream(stream2.cuda_stream)
+                d_out2 = torch.zeros_like(d_out)
+                n_l = max(args.steps, 200)
+                srcs = [d_in.data_ptr()] * n_l
+                dsts = [(d_out if k % 2 == 0 else d_out2).data_ptr() for k in range(n_l)]
+                ctx.flush()
+                torch.cuda.synchronize()
+
+                def lanes_pass():
+                    ea, eb, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
+                    ea.record(stream)
+                    stream2.wait_event(ea)
+                    S.forward_y_lanes_dev([ctx, ctx2], srcs, W, dsts, W, W, H)
+                    e2.record(stream2)
+                    stream.wait_event(e2)
+                    eb.record(stream)
+                    eb.synchronize()
+                    return ea.elapsed_time(eb) / n_l
+                t_l = time.perf_counter()
+                while time.perf_counter() - t_l < 0.3:
+                    lanes_pass()
+                ms_l = min(lanes_pass() for _ in range(3))
+                same = bool(torch.equal(d_out, d_out2)) and zlib.crc32(d_out2.cpu().numpy()[0].tobytes()) == crcs[0]
+                out["two_lanes"] = {"ms_per_step": round(ms_l, 4), "value": round(W * H / ms_l / 1e3, 2), "unit": "MPix/s",
+                                    "frac": round(S.FLOP_PER_PIXEL * W * H / (ms_l * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    "vs_one_lane": round(ms_l / (elapsed / args.steps * 1e3), 3), "outputs_equal_the_headline_planes": same,
+                                    "what": f"{n_l} planes alternately on two contexts / streams of the one GPU (srcnn_forward_y_lanes_dev), "
+                                            "HIP events around the pass, best of 3; never `value`"}
+            except Exception as e:             # noqa: BLE001 -- a secondary leg must not take the measured line with it
+                out["two_lanes"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+            finally:
+                if ctx2 is not None:
+                    ctx2.close()
+                torch.cuda.set_stream(stream)
         if world == 1 and args.path == "fused" and not stripe and not args.no_e2e:
             try:
                 # SURVEY 8d's secondary metric, never `value`: the same planes from and to HOST memory, PCIe-inclusive

@@ -237,6 +237,18 @@ int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx,
                                  uint8_t *const *dst, size_t dst_stride,
                                  int width, int height, int n_frames);
 
+/* DEVICE-resident planes of a stream over n_ctx contexts used as LANES: plane f is one fused launch on the stream of
+ * ctxs[f % n_ctx] (d_src[f] / d_dst[f] on that context's GPU), with seam deferral inside the call; asynchronous -- the call
+ * returns with every plane queued and every lane flushed, srcnn_synchronize each context to wait.  Two contexts ON ONE GPU
+ * are two lanes of that GPU: the next plane's kernel fills the compute units the previous plane's slowest workgroups leave
+ * idle, which is most of what small planes lose (576x576: 0.60 -> 0.75 of the f32 MFMA peak, 1920x1080 0.861 -> 0.872;
+ * 3840x2160: nothing to gain).  Same bytes as srcnn_forward_y_dev plane by plane.  No ordering between the lanes: planes
+ * that depend on each other belong on one context. */
+int srcnn_forward_y_lanes_dev(srcnn_ctx *const *ctxs, int n_ctx,
+                              const uint8_t *const *d_src, size_t src_stride,
+                              uint8_t *const *d_dst, size_t dst_stride,
+                              int width, int height, int n_planes);
+
 /* ONE width x height host plane row-striped over n_ctx contexts: context k
  * uploads only its own rows srcnn_stripe_rows(height, n_ctx, k), the 6 halo rows
  * per boundary travel device to device into small buffers of their own, and each
@@ -392,15 +404,15 @@ int srcnn_set_fixup_strict(srcnn_ctx *ctx, int on);
 int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
 /* THE PER-PIXEL THRESHOLD (round 6; both byte-exact modes).  The rounding noise of a pixel scales with ITS OWN activations, so
  * the strip kernels flag pixel x against
- *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs_local),        abs_local = 8 * 2^-24 * 256 = 1.22e-4,
+ *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs_local),        abs_local = 16 * 2^-24 * 256 = 2.44e-4,
  * S1(x) = the sum over the pixel's 5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c -- carried through the kernels in five
- * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.45 (k = 1.8 with the default margin 4;
- * REFBYTES16: 8/6 of it, the ratio of the two modes' global thresholds): thr stays 1.73 x above the deviation of EVERY window the
- * adversarial searches have produced -- searches on exactly that quantity included (profiles/r06/fixup_adversarial_ratio.txt,
- * adversarial_gpu_ratio.txt) -- which is the factor the global delta keeps over the worst of them; content stays below 0.37 thr
- * (fixup_local_scale.txt).  0.54-0.63 x the flagged pixels on ordinary content (0.24 x on sparse, 0.99 x on very bright content).
- * The monitor and the device-side net compare each recomputed pixel's deviation with ITS threshold (rerun above 1/2).
- * k_local = 0: the one global threshold of rounds 3-5.
+ * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.3875 (k = 1.55 with the default margin 4;
+ * REFBYTES16: k = 2.1, its kernel's noise is wider): thr stays 1.73 x above the deviation of EVERY window the adversarial
+ * searches have produced -- the factor the global delta keeps over the worst of them; the searches climb on exactly that
+ * quantity, on the CPU models and on the kernels themselves (profiles/r06/fixup_adversarial_ratio.txt, adversarial_gpu_ratio.txt) --
+ * and content stays below 0.4 thr (fixup_local_scale.txt).  0.57-0.65 x the flagged pixels on ordinary content (0.27 x on sparse
+ * content, 0.98 x on very bright content).  The monitor and the device-side net compare each recomputed pixel's deviation with
+ * ITS threshold (rerun above 1/2).  k_local = 0: the one global threshold of rounds 3-5.
  * srcnn_fixup_local_stats: *k = margin * k_local in effect for the context's mode, *max_ratio = the largest
  * |v_kernel - v_reference| / thr(x) met on a flagged pixel since the context was created (synchronises the stream). */
 int srcnn_set_fixup_local(srcnn_ctx *ctx, float k_local);

@@ -30,7 +30,7 @@ __all__ = [
     "Convolution99", "Convolution11", "Convolution55", "Convolution99x11", "default_context",
     "MODE_MFMA", "MODE_EXACT", "MODE_SPLIT16", "MODE_REFBYTES", "MODE_REFBYTES16", "FLOP_PER_PIXEL",
     "ERR_INVALID", "ERR_HIP", "ERR_NOMEM", "ERR_NODEVICE", "ERR_STATE",
-    "stripe_rows", "forward_y_frames_multi", "forward_y_striped", "forward_y_striped_dev",
+    "stripe_rows", "forward_y_frames_multi", "forward_y_lanes_dev", "forward_y_striped", "forward_y_striped_dev",
 ]
 
 _PKG = Path(__file__).resolve().parent
@@ -148,6 +148,7 @@ def load_library() -> C.CDLL:
         "srcnn_process_bgr_dev": ([vp, vp, sz, i, i, C.c_float, vp, sz], i),
         "srcnn_stripe_rows": ([i, i, i, C.POINTER(i), C.POINTER(i)], i),
         "srcnn_forward_y_frames_multi": ([C.POINTER(vp), i, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
+        "srcnn_forward_y_lanes_dev": ([C.POINTER(vp), i, C.POINTER(vp), sz, C.POINTER(vp), sz, i, i, i], i),
         "srcnn_forward_y_striped": ([C.POINTER(vp), i, _u8p, sz, _u8p, sz, i, i], i),
         "srcnn_forward_y_striped_frames": ([C.POINTER(vp), i, C.POINTER(_u8p), sz, C.POINTER(_u8p), sz, i, i, i], i),
         "srcnn_forward_y_striped_dev": ([C.POINTER(vp), i, C.POINTER(vp), sz, C.POINTER(vp), sz, i, i], i),
@@ -169,7 +170,7 @@ ABI_SYMBOLS = (
     "srcnn_conv55_dev", "srcnn_conv99x11_to_dev", "srcnn_conv55_from_dev", "srcnn_dev_alloc", "srcnn_dev_free",
     "srcnn_dev_download", "srcnn_dev_upload", "srcnn_ipc_export", "srcnn_ipc_open", "srcnn_ipc_close", "srcnn_query_plan", "srcnn_fixup_stats", "srcnn_set_fixup_strict", "srcnn_set_fixup_margin", "srcnn_set_fixup_local", "srcnn_fixup_local_stats", "srcnn_set_seam_deferral", "srcnn_flush", "srcnn_scaled_size", "srcnn_bgr2ycrcb", "srcnn_ycrcb2bgr",
     "srcnn_resize_cubic", "srcnn_process_bgr", "srcnn_process_bgr_dev",
-    "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_striped", "srcnn_forward_y_striped_frames", "srcnn_forward_y_striped_dev",
+    "srcnn_stripe_rows", "srcnn_forward_y_frames_multi", "srcnn_forward_y_lanes_dev", "srcnn_forward_y_striped", "srcnn_forward_y_striped_frames", "srcnn_forward_y_striped_dev",
 )
 
 
@@ -601,6 +602,18 @@ def forward_y_frames_multi(ctxs: Sequence[Context], frames, out=None):
     ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_frames_multi(_ctx_array(ctxs), len(ctxs), srcs, w, dsts, w,
                                                                           w, h, n))
     return out
+
+
+def forward_y_lanes_dev(ctxs: Sequence[Context], d_src_ptrs, src_stride, d_dst_ptrs, dst_stride, width, height):
+    """Device-resident planes of a stream over the contexts used as lanes: plane f on ctxs[f % len(ctxs)], asynchronous
+    (srcnn_forward_y_lanes_dev).  Two contexts on one GPU = two lanes of it."""
+    n = len(d_src_ptrs)
+    if n == 0 or len(d_dst_ptrs) != n:
+        raise ValueError("need as many output planes as input planes, at least one")
+    srcs = (C.c_void_p * n)(*[int(p) for p in d_src_ptrs])
+    dsts = (C.c_void_p * n)(*[int(p) for p in d_dst_ptrs])
+    ctxs[0]._check_multi(ctxs, load_library().srcnn_forward_y_lanes_dev(_ctx_array(ctxs), len(ctxs), srcs, src_stride, dsts, dst_stride,
+                                                                       width, height, n))
 
 
 def forward_y_striped(ctxs: Sequence[Context], src, dst=None):

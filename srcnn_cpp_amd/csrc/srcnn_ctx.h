@@ -139,15 +139,20 @@ public:
 constexpr float kFixMargin = 4.f;
 // ... its absolute term (roundings at the output's own magnitude: fixup_delta()).
 // The PER-PIXEL threshold (round 6; srcnn_set_fixup_local):  thr(x) = min(delta, margin * kFixLocal * 2^-24 * S1(x) + kFixAbsLocal),
-// S1 = the pixel's local scale (srcnn_kernels.h, l3_row_is_scale()).  The pair (k = 4 * kFixLocal = 1.8, abs = 8 * 2^-24 * 256 =
-// 1.22e-4) is the cheapest one on ordinary content among those that keep thr 1.73 x above the deviation of EVERY window the
-// adversarial searches have produced -- the factor the global delta keeps over the worst of them -- (the noise has a part that
-// does not shrink with S1: with abs = 6.1e-5 the windows of small local scale ask for k = 2.4; profiles/r06/fixup_local_scale.txt,
-// fixup_adversarial_ratio.txt); content stays below 0.37 thr, i.e. below the 1/2 at which the device-side net takes over.
+// S1 = the pixel's local scale (srcnn_kernels.h, l3_row_is_scale()).  How (k, abs) = (4 * kFixLocal, kFixAbsLocal) were chosen
+// (profiles/r06/README.md, "the per-pixel threshold"): the noise has a part that does not shrink with S1 -- with abs = 6.1e-5 the
+// windows of small local scale ask for k = 2.4, with 2.44e-4 for 1.48 -- and among the pairs that keep
+//   (R1) thr >= 1.73 x the deviation of EVERY window an adversarial search has produced (the factor the global delta keeps over the
+//        worst of them), the searches climbing on exactly that quantity: 241 M point evaluations on the CPU models
+//        (fixup_adversarial_ratio.txt: k >= 1.480; random models <= 0.78), 1.5 M window evaluations on the kernel itself
+//        (adversarial_gpu_ratio.txt: 1.480; split-f16 kernel: 2.023), and
+//   (R2) thr >= 2.5 x the largest deviation on content (it then stays below 0.4 thr, short of the 1/2 at which the device-side net
+//        redoes a launch): 1.485 (sparse bright strokes on a dark ground; split-f16 kernel: 1.777),
+// abs = 16 * 2^-24 * 256 = 2.44e-4 is the cheapest on ordinary content.  k = 1.55 / 2.1 keep 4-5 % over what those figures ask for.
 constexpr float kFixAbsTerm = 4.f * 256.f / 16777216.f;
-constexpr float kFixAbsLocal = 8.f * 256.f / 16777216.f;
-constexpr float kFixLocal = 0.45f;
-constexpr float kFixLocal16 = kFixLocal * (8.f / 6.f);      // the ratio of the two modes' global thresholds, until the GPU-side search says otherwise
+constexpr float kFixAbsLocal = 16.f * 256.f / 16777216.f;
+constexpr float kFixLocal = 0.3875f;
+constexpr float kFixLocal16 = 0.525f;      // SRCNN_MODE_REFBYTES16: the split-f16 kernel's noise is wider (k = 2.1)
 
 struct srcnn_ctx {
     int device = 0;

@@ -199,6 +199,88 @@ __device__ __forceinline__ void exact_layer2_quarter(In a, const float *wraw, in
     }
 }
 
+// ---- the same two loops with the weights in LDS (round 6: fix_apply_kernel) --------------------------------------------
+// The scalar-load form above fetches a tap's weights ONE tap ahead -- all the scalar registers allow -- and the tables (W1
+// transposed 20.7 KB + W2 transposed 8 KB) do not fit the 16 KB scalar cache: every tap is an L2 round trip of 300-500 cycles
+// behind ~160 cycles of arithmetic.  Five workgroups per CU hide that at full load and nothing hides it on a small plane, whose
+// few hundred items are ONE round of the draw: an item took ~45 us whatever the occupancy (fix_apply 49.5 us on a 1920x1080 plane
+// for 646 items, 101 us on 3840x2160 for 2,665: 75 % of the vector ALU's issue rate).  Here a workgroup stages both tables in LDS
+// once (29 KB) and every lane reads a tap's 32 weights as eight broadcast ds_read_b128 (all lanes one address: no bank conflict),
+// two taps ahead -- LDS returns in order, so the waits are counted, not drained.  Same products, same order, same roundings.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PITCH>
+__device__ __forceinline__ void exact_layer1_half_lds(const float *win, const float *s_w1t /* LDS [82][64] */, const float *b1g, int hh, f32x2 (&acc)[16])
+{
+    const cfloat_p b1 = as_constant(b1g) + 32 * hh;
+    const f32x4 *wrow = reinterpret_cast<const f32x4 *>(s_w1t + 32 * hh);      // tap t at wrow[16 t .. 16 t + 7]
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = f32x2{0.f, 0.f};
+    float ya[9], yb[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) ya[j] = win[j];
+    f32x4 wc[8], wn[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wc[q] = wrow[q];
+    auto row = [&](const float (&ycur)[9], float (&ynext)[9], const float *next) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wn[q] = wrow[16 * (j + 1) + q];            // tap (i, j + 1), or (i + 1, 0); the table is padded by one tap
+            if (j == 0) {
+#pragma unroll
+                for (int jj = 0; jj < 9; ++jj) ynext[jj] = next[jj];
+            }
+            const f32x2 yy = {ycur[j], ycur[j]};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const f32x2 a = {wc[c >> 1][2 * (c & 1)], wc[c >> 1][2 * (c & 1) + 1]};
+                const f32x2 p0 = a * yy;
+                acc[c] = acc[c] + p0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wc[q] = wn[q];
+        }
+        wrow += 16 * 9;
+    };
+#pragma unroll 1
+    for (int i = 0; i < 8; i += 2) {
+        row(ya, yb, win + (i + 1) * PITCH);
+        row(yb, ya, win + (i + 2) * PITCH);
+    }
+    row(ya, yb, win + 8 * PITCH);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const f32x2 bv = {b1[2 * c], b1[2 * c + 1]};
+        f32x2 a = acc[c] + bv;
+        a.x = (a.x < 0) ? 0.f : a.x;
+        a.y = (a.y < 0) ? 0.f : a.y;
+        acc[c] = a;
+    }
+}
+template <class In>
+__device__ __forceinline__ void exact_layer2_quarter_lds(In a, const float *s_w2t /* LDS [65][32] */, int hh, int in0, f32x2 (&r)[8])
+{
+    const f32x4 *w2t = reinterpret_cast<const f32x4 *>(s_w2t + in0 * 32 + 16 * hh);      // input i at w2t[8 i .. 8 i + 3]
+    f32x4 wc[4], wn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wc[q] = w2t[q];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wn[q] = w2t[8 * (i + 1) + q];                  // (behind the last channel: the table's padding row)
+        const float ai = a(i);
+        const f32x2 aa = {ai, ai};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 wa = {wc[k >> 1][2 * (k & 1)], wc[k >> 1][2 * (k & 1) + 1]};
+            const f32x2 p0 = wa * aa;
+            r[k] = r[k] + p0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wc[q] = wn[q];
+    }
+}
+
 // The whole-plane kernel keeps the register form: the 81 window values of the lane's pixel in registers, one layer-1 channel
 // after the other, each activation folded into the 32 layer-2 sums as soon as it exists.  (Measured on one box, 3840x2160:
 // this form 1.90 ms, the tap-outer form above from an LDS tile 2.13 ms packed / 2.06 ms unpacked -- the opposite order of
@@ -468,12 +550,24 @@ __global__ __launch_bounds__(256) void fix_collect_kernel(const FixParams p)
 // 0-3, 4-7, 8-11): 1.5 x the positions of round 3's one pass, on the rare flat / periodic content only.
 // RERUN = false: fix_apply_kernel (the work lists, the monitor, the verdict).
 // RERUN = true:  fix_rerun_kernel (every tile of the launch as a dense tile, if the verdict asks for it).
-template <bool RERUN>
+template <bool RERUN, bool LDSW = false>
 __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
 {
+    // LDSW: both weight tables of layers 1-2 staged in LDS once per workgroup (exact_layer1_half_lds)
+    __shared__ __attribute__((aligned(16))) float s_w1t[LDSW ? 82 * 64 : 4];
+    __shared__ __attribute__((aligned(16))) float s_w2t[LDSW ? 65 * 32 : 4];
+    if constexpr (LDSW) {
+        for (int i = threadIdx.x; i < 81 * 64; i += 256) s_w1t[i] = p.wraw[10177 + i];
+        for (int i = 81 * 64 + threadIdx.x; i < 82 * 64; i += 256) s_w1t[i] = 0.f;
+        for (int i = threadIdx.x; i < 64 * 32; i += 256) s_w2t[i] = p.wraw[8129 + i];
+        for (int i = 64 * 32 + threadIdx.x; i < 65 * 32; i += 256) s_w2t[i] = 0.f;
+    }
     __shared__ float Fs[FIX_HALF][33];      // per position: the layer-2 chains between the two halves, then the activations
-    __shared__ float s_y[FIX_GROUP * 169 > FIX_DWIN_H * FIX_DWIN_W ? FIX_GROUP * 169 : FIX_DWIN_H * FIX_DWIN_W];   // the luma the item's positions read
-    __shared__ double s_tp[FIX_GROUP][32];  // scattered items: the 25-term double sums per (pixel, channel)
+    // scattered items: the 25-term double sums per (pixel, channel) -- in the luma window's memory, which layers12() is done with
+    // by then (with the weights in LDS a workgroup must stay below 160 KB / 3)
+    __shared__ __attribute__((aligned(8))) float s_y[FIX_GROUP * 169 > FIX_DWIN_H * FIX_DWIN_W ? FIX_GROUP * 169 : FIX_DWIN_H * FIX_DWIN_W];   // the luma the item's positions read
+    static_assert(sizeof(s_y) >= sizeof(double) * FIX_GROUP * 32, "s_tp lives in s_y");
+    double (*s_tp)[32] = reinterpret_cast<double (*)[32]>(s_y);
     __shared__ float s_w3[800];
     __shared__ float s_sp[FIX_GROUP][32];   // scattered items: the local scale's per-channel terms a_c * sum_25 F_c
     __shared__ float s_amax[32];            // a_c = max_tap |W3[c][tap]|
@@ -489,10 +583,14 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
     const int q = tid & (FIX_HALF - 1);
     const int hh = __builtin_amdgcn_readfirstlane(tid >> 7);
     for (int i = tid; i < 800; i += 256) s_w3[i] = p.wraw[7329 + i];
-    if (!RERUN && tid < 32) {
-        float a = 0.f;
-        for (int t = 0; t < 25; ++t) a = fmaxf(a, fabsf(p.wraw[7329 + tid * 25 + t]));
-        s_amax[tid] = a;
+    if constexpr (!RERUN) {      // a_c from the table just staged (not 25 global loads per thread in front of the first item)
+        __syncthreads();
+        if (tid < 32) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 25; ++t) a = fmaxf(a, fabsf(s_w3[tid * 25 + t]));
+            s_amax[tid] = a;
+        }
     }
     if (tid == 0) { s_changed = 0; s_maxdev = 0; s_maxratio = 0; }
     const int W = p.width, H = p.height;
@@ -506,7 +604,8 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
     // `win`: the luma under tap (0, 0) of the lane's position in s_y, window rows PITCH apart, border already replicated.
     auto layers12 = [&](const float *win, auto pitch) {
         f32x2 acc[16];
-        exact_layer1_half<decltype(pitch)::value>(win, p.wraw, hh, acc);
+        if constexpr (LDSW) exact_layer1_half_lds<decltype(pitch)::value>(win, s_w1t, p.wraw, hh, acc);
+        else exact_layer1_half<decltype(pitch)::value>(win, p.wraw, hh, acc);
         auto own = [&](int i) { return (i & 1) ? acc[i >> 1].y : acc[i >> 1].x; };
         auto theirs = [&](int i) { return Fs[q][i]; };
         f32x2 r[8];
@@ -518,8 +617,13 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
             for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = acc[k].x; Fs[q][2 * k + 1] = acc[k].y; }
         }
         __syncthreads();
-        if (hh == 0) exact_layer2_quarter(own, p.wraw, 0, 0, r);
-        else exact_layer2_quarter(theirs, p.wraw, 1, 0, r);
+        if constexpr (LDSW) {
+            if (hh == 0) exact_layer2_quarter_lds(own, s_w2t, 0, 0, r);
+            else exact_layer2_quarter_lds(theirs, s_w2t, 1, 0, r);
+        } else {
+            if (hh == 0) exact_layer2_quarter(own, p.wraw, 0, 0, r);
+            else exact_layer2_quarter(theirs, p.wraw, 1, 0, r);
+        }
         __syncthreads();                     // the hh = 1 lanes are done reading
         // input channels 32-63: the hh = 1 lane's
         if (hh == 1) {
@@ -527,8 +631,13 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
             for (int k = 0; k < 16; ++k) { Fs[q][2 * k] = acc[k].x; Fs[q][2 * k + 1] = acc[k].y; }
         }
         __syncthreads();
-        if (hh == 1) exact_layer2_quarter(own, p.wraw, 1, 32, r);
-        else exact_layer2_quarter(theirs, p.wraw, 0, 32, r);
+        if constexpr (LDSW) {
+            if (hh == 1) exact_layer2_quarter_lds(own, s_w2t, 1, 32, r);
+            else exact_layer2_quarter_lds(theirs, s_w2t, 0, 32, r);
+        } else {
+            if (hh == 1) exact_layer2_quarter(own, p.wraw, 1, 32, r);
+            else exact_layer2_quarter(theirs, p.wraw, 0, 32, r);
+        }
         __syncthreads();                     // the hh = 0 lanes are done reading
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -724,9 +833,11 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
 }
 
 __global__ __launch_bounds__(256, 5) void fix_apply_kernel(const FixParams p) { fix_kernel_body<false>(p); }
+// ... the weights in LDS: 54 KB and <= 168 registers, three workgroups per CU
+__global__ __launch_bounds__(256, 3) void fix_apply_lds_kernel(const FixParams p) { fix_kernel_body<false, true>(p); }
 __global__ __launch_bounds__(256, 5) void fix_rerun_kernel(const FixParams p) { fix_kernel_body<true>(p); }
 
-hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, hipStream_t st)
+hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, bool lds_weights, hipStream_t st)
 {
     const int rows = p.row_end - p.row_begin;
     const int tiles_x = (p.width + FIX_TILE - 1) / FIX_TILE, bands = (rows + FIX_TILE - 1) / FIX_TILE;
@@ -734,8 +845,10 @@ hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, hipStream
     hipLaunchKernelGGL(fix_collect_kernel, dim3((unsigned)(bands * segs * p.n_frames)), dim3(256), 0, st, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // every workgroup the GPU holds at once (5 per CU: <= 102 VGPRs, 26 KB of LDS each); they draw items from FIX_NEXT_ITEM
-    hipLaunchKernelGGL(fix_apply_kernel, dim3((unsigned)(5 * n_cu)), dim3(256), 0, st, p);
+    // every workgroup the GPU holds at once (5 per CU: <= 102 VGPRs, 26 KB of LDS each; with the weights in LDS 3 per CU: 55 KB,
+    // <= 168 VGPRs); they draw items from FIX_NEXT_ITEM
+    if (lds_weights) hipLaunchKernelGGL(fix_apply_lds_kernel, dim3((unsigned)(3 * n_cu)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(fix_apply_kernel, dim3((unsigned)(5 * n_cu)), dim3(256), 0, st, p);
     e = hipGetLastError();
     if (e != hipSuccess || !with_rerun) return e;
     hipLaunchKernelGGL(fix_rerun_kernel, dim3((unsigned)(5 * n_cu)), dim3(256), 0, st, p);

@@ -190,7 +190,8 @@ __device__ __forceinline__ uint8_t fix_src_at(const FixParams &p, int frame, int
 }
 
 // fix_collect_kernel, fix_apply_kernel, and behind them fix_rerun_kernel when `with_rerun` (srcnn_set_fixup_strict, the default)
-hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, hipStream_t st);
+// lds_weights: fix_apply_lds_kernel (both weight tables of layers 1-2 in LDS, 3 workgroups per CU) instead of the scalar-load form
+hipError_t launch_fixup(const FixParams &p, int n_cu, bool with_rerun, bool lds_weights, hipStream_t st);
 constexpr int FIX_BATCH_FRAMES = 16;      // frames per fix-up launch at most (pixel codes stay below 2^32 up to 16 x 16384 x 16384)
 size_t fixup_list_entries(int width, int rows, int n_frames, size_t *dense_entries);
 

@@ -354,7 +354,8 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         // the fix-up batch in the reference's arithmetic (no threshold involved).  No host read: the stream is never stalled.
         static const char *env_rerun = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FORCE_RERUN");     // test knob: every launch is redone
         f.rerun_above = (env_rerun && std::atoi(env_rerun)) ? -1.f : c->fix_strict ? 0.5f : INFINITY;
-        HIP_TRY(c, launch_fixup(f, c->n_cu, c->fix_strict, c->stream));
+        static const char *env_lds = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FIX_LDS");           // A/B knob: 0 = the scalar-load fix_apply of rounds 3-5
+        HIP_TRY(c, launch_fixup(f, c->n_cu, c->fix_strict, !(env_lds && std::atoi(env_lds) == 0), c->stream));
     }
     return SRCNN_OK;
 }

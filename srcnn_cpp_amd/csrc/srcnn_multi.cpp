@@ -413,6 +413,39 @@ int srcnn_forward_y_striped_frames(srcnn_ctx *const *ctxs, int n_ctx, const uint
     });
 }
 
+/* Device-resident planes of a STREAM over n_ctx contexts used as LANES: plane f runs on ctxs[f % n_ctx], on that context's
+ * stream, as one fused launch whose seam blocks ride behind the lane's next plane (seam deferral inside the call; the last
+ * plane of every lane is flushed before the call returns).  Nothing waits: the call returns with everything queued.
+ * TWO CONTEXTS ON ONE GPU are two lanes of that GPU: while the slowest compute units of one plane's launch finish, the other
+ * lane's next kernel is already being dispatched onto the ones that are free -- the idle tail and the launch boundary of a
+ * launch, 2 % of a 3840x2160 step but 25 % of a 576x576 one, are filled (profiles/r06/two_lane_probe.txt: 576x576 0.60 ->
+ * 0.75 of the f32 MFMA peak, 1280x720 0.80 -> 0.83, 1920x1080 0.861 -> 0.872, 3840x2160 unchanged).  Contexts on different
+ * GPUs are frame sharding for planes that already live there (d_src[f] / d_dst[f] on the device of ctxs[f % n_ctx]). */
+int srcnn_forward_y_lanes_dev(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *d_src, size_t src_stride,
+                              uint8_t *const *d_dst, size_t dst_stride, int width, int height, int n_planes)
+{
+    int rc = check_ctx_set(ctxs, n_ctx);
+    if (rc) return rc;
+    if (!d_src || !d_dst || n_planes <= 0) return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_lanes_dev: bad arguments");
+    for (int f = 0; f < n_planes; ++f)
+        if (!d_src[f] || !d_dst[f]) return fail(ctxs[0], SRCNN_ERR_INVALID, "forward_y_lanes_dev: null plane %d", f);
+    // one host thread queues everything: a launch is a few microseconds of host time, and the order of the lanes' submissions
+    // is what lets their kernels interleave on one GPU
+    std::vector<char> was(n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        was[(size_t)k] = ctxs[k]->defer_seams ? 1 : 0;
+        ctxs[k]->defer_seams = true;
+    }
+    for (int f = 0; f < n_planes && !rc; ++f)
+        rc = srcnn_forward_y_dev(ctxs[f % n_ctx], d_src[f], src_stride, 0, d_dst[f], dst_stride, 0, width, height, 1, nullptr);
+    for (int k = 0; k < n_ctx; ++k) {
+        ctxs[k]->defer_seams = was[(size_t)k] != 0;
+        const int r = srcnn_flush(ctxs[k]);       // every lane's last plane is complete on its stream once the call has returned
+        if (!rc) rc = r;
+    }
+    return rc;
+}
+
 int srcnn_halo_transport(const srcnn_ctx *c) { return c ? c->halo_transport : SRCNN_ERR_INVALID; }
 
 int srcnn_forward_y_frames_multi(srcnn_ctx *const *ctxs, int n_ctx, const uint8_t *const *src, size_t src_stride,

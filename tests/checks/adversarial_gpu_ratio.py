@@ -30,7 +30,7 @@ from srcnn_cpp_amd.synth import synth_luma  # noqa: E402
 
 R, C = 13, 6
 EPS = 2.0 ** -24
-ABS = 8 * EPS * 256            # kFixAbsLocal of srcnn_ctx.h; argv[4] / argv[5]: another absolute term for the float32 / the split-f16 kernel
+ABS = 16 * EPS * 256           # kFixAbsLocal of srcnn_ctx.h; argv[4] / argv[5]: another absolute term for the float32 / the split-f16 kernel
 ABS_OF = {}                    # per kernel
 ABS_TABLE = [4 * EPS * 256, 8 * EPS * 256, 12 * EPS * 256, 16 * EPS * 256, 24 * EPS * 256]
 blob = S.load_weights()

@@ -29,7 +29,7 @@ import oracle  # noqa: E402
 import srcnn_cpp_amd as S  # noqa: E402
 from fixup_adversarial import random_model, starts  # noqa: E402
 
-ABS = 4 * 2.0 ** -24 * 256       # kFixAbsTerm of srcnn_ctx.h unless argv[6] says otherwise (the fit of (k, abs): profiles/r06/)
+ABS = 16 * 2.0 ** -24 * 256      # kFixAbsLocal of srcnn_ctx.h unless argv[6] says otherwise (the fit of (k, abs): profiles/r06/)
 GAIN = 1.73
 
 
@@ -96,6 +96,9 @@ def main():
     for fn in ("adversarial_windows.npz", "adversarial_windows_gpu.npz"):
         z = np.load(ROOT / "tests" / "golden" / fn)
         old += [z[k] for k in z.files if z[k].dtype == np.uint8 and z[k].ndim == 3 and z[k].shape[1:] == (13, 13) and "random" not in k]
+    gpu_ratio = ROOT / "tests" / "golden" / "adversarial_windows_gpu_ratio.npz"        # tests/checks/adversarial_gpu_ratio.py: the same climb on the GPU
+    if gpu_ratio.exists():
+        old.append(np.load(gpu_ratio)["mfma_windows"])
     old = np.concatenate(old)
     w, r, v, ev_total = attack(blob, n_ship, rng, "shipped model (convdata.h)", log, seeds=old)
     fixture = {"shipped_windows": w[:64], "shipped_kappa": r[:64], "shipped_vals": v[:64], "gain": np.float32(GAIN), "abs_term": np.float32(ABS)}

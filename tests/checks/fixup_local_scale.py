@@ -9,8 +9,8 @@ strip kernel could carry at (almost) no MFMA cost:
   S1(x) = sum over the 5x5 window of U,  U = sum_c a_c * F_c,  a_c = max_tap |W3[c][tap]|   (one more layer-3 accumulator row + a box sum)
   S2(x) = sum_tap sum_c |W3[c][tap]| * F_c(x + tap)                                          (25 more rows: the exact abs-weight sum)
 
-For every content class this prints the k a threshold k * 2^-24 * S1 + abs needs to stay 3.1 x above every deviation of the class
-(the factor the global delta keeps over the largest deviation met on content), for several absolute terms, and what a (k, abs)
+For every content class this prints the k a threshold k * 2^-24 * S1 + abs needs to stay 2.5 x above every deviation of the class
+(content then stays below 0.4 thr, short of the 1/2 at which the device-side net redoes a launch: rule R2 of srcnn_ctx.h), for several absolute terms, and what a (k, abs)
 pair then flags against the global threshold.  (S2, the exact abs-weight sum, tracks S1 within a few per cent on every class:
 round 6's first run of this script; it would cost 25 accumulator rows instead of 5 idle ones.)  The adversarial side of the
 same question: tests/checks/fixup_adversarial_ratio.py.
@@ -86,8 +86,8 @@ classes = {
 }
 
 delta_now = 1.376e-3          # fixup_delta() of the shipped model at the default margin 4 (tests/test_refbytes_model.py)
-GAIN_CONTENT = 3.1            # the factor the global delta keeps over the largest deviation met on content (1.376e-3 / 4.4e-4)
-ABS_CANDIDATES = [4 * EPS * 256, 6 * EPS * 256, 8 * EPS * 256, 12 * EPS * 256]
+GAIN_CONTENT = 2.5            # rule R2 of srcnn_ctx.h: content stays below 0.4 thr (the global delta happens to keep 3.1 on content)
+ABS_CANDIDATES = [4 * EPS * 256, 8 * EPS * 256, 12 * EPS * 256, 16 * EPS * 256, 24 * EPS * 256]
 rows = []
 for name, y in classes.items():
     F = oracle.gpuorder_conv99x11(y, w1, b1, w2, b2)
@@ -109,7 +109,7 @@ for a in ABS_CANDIDATES:
     print(f"  abs {a:.3e}: k >= {k:.3f}")
 
 # what a (k, abs) pair flags: the mean threshold over the live pixels of a class against the global delta (flagged fraction ~ 2 x mean threshold)
-K_ABS = [(float(sys.argv[2]), float(sys.argv[3]))] if len(sys.argv) > 3 else [(2.4, 4 * EPS * 256), (1.8, 8 * EPS * 256), (1.65, 12 * EPS * 256)]
+K_ABS = [(float(sys.argv[2]), float(sys.argv[3]))] if len(sys.argv) > 3 else [(2.4, 4 * EPS * 256), (1.8, 8 * EPS * 256), (1.55, 16 * EPS * 256)]
 for k, a in K_ABS:
     print(f"\nthr = min(delta, {k} * 2^-24 * S1 + {a:.3e}):  mean threshold / delta per class (= flagged pixels against the global threshold's)")
     for name, lv, d, s1 in rows:

@@ -92,8 +92,10 @@ while time.time() - t0 < budget:
 ctx.set_mode(S.MODE_MFMA)
 st = ctx.fixup_stats()
 assert st["max_dev"] < 0.5 * st["delta"], st
+k_eff, ratio = ctx.fixup_local_stats() if hasattr(ctx, "fixup_local_stats") else (0.0, 0.0)
+assert ratio < 0.5 or st["exact_reruns"] >= 1, (k_eff, ratio, st)      # above half a pixel's own threshold the net must have acted
 print(f"refbytes: every plane bytewise equal to the reference arithmetic; {st['scattered_pixels']} pixels recomputed one by one, "
       f"{st['dense_tiles']} tiles whole, {st['bytes_changed']} bytes changed; largest |v_mfma - v_ref| seen {st['max_dev']:.2e} "
-      f"against delta {st['delta']:.2e}")
+      f"against delta {st['delta']:.2e}; largest deviation over the pixel's own threshold (k = {k_eff:.2f}) {ratio:.3f}; launches redone by the net: {st['exact_reruns']}")
 print(f"soak ok: {n} random planes and {n_batches} REFBYTES batches of 2-21 frames in {time.time() - t0:.0f} s (seed {seed}); worst pre-clamp error / max(1, |ref|max/255): "
       f"mfma {worst['mfma']:.2e}, split16 {worst['split16']:.2e}")

@@ -60,9 +60,10 @@ while time.time() - t0 < budget:
                     raise AssertionError((mode, n, w, h, int(kind), s1, s2, s3, len(ys), st, "rows", int(ys.min()), int(ys.max()), "cols", int(xs.min()),
                                           int(xs.max()), "repeat call differs from the oracle in", int((again != r2).sum()),
                                           "the two oracle runs differ in", int((r2 != r_out).sum())))
-            ratio = st["max_dev"] / st["delta"] if st["delta"] > 0 else 0.0
-            # above delta / 2 the device-side net must have redone the launch (the bytes above are already checked)
-            assert ratio < 0.5 or st["exact_reruns"] >= 1, (mode, n, st, s1, s2, s3)
+            # round 6: the largest deviation over the flagged pixel's OWN threshold (srcnn_fixup_local_stats); above 1/2 the
+            # device-side net must have redone the launch (the bytes above are already checked)
+            ratio = ctx.fixup_local_stats()[1]
+            assert ratio < 0.5 or st["exact_reruns"] >= 1, (mode, n, st, ratio, s1, s2, s3)
             reruns += int(st["exact_reruns"] >= 1)
             if mode == S.MODE_REFBYTES:
                 worst = max(worst, ratio)
@@ -70,7 +71,7 @@ while time.time() - t0 < budget:
                 worst16, n16 = max(worst16, ratio), n16 + 1
     n += 1
 print(f"soak_models ok: {n} random models x planes in {time.time() - t0:.0f} s ({n16} of them also in REFBYTES16); every plane bytewise equal "
-      f"to the reference arithmetic; largest monitored deviation / threshold = {worst:.3f} (REFBYTES16: {worst16:.3f}); "
-      f"{reruns} launches were over delta / 2 and redone by the device-side net"
+      f"to the reference arithmetic; largest monitored deviation / the pixel's own threshold = {worst:.3f} (REFBYTES16: {worst16:.3f}); "
+      f"{reruns} launches were over half a threshold and redone by the device-side net"
       + (f"; ORACLE ANOMALIES (first run of oracle.forward_y disagreed with a second run AND with the GPU; (n, w, h, bytes, rows)): {oracle_flakes}" if oracle_flakes else "")
       + f"; the oracle wrapper's own double runs disagreed {oracle.anomalies} times")

@@ -114,36 +114,42 @@ def test_windows_the_gpu_search_found_reproduce_on_the_cpu_model(weights_blob):
 
 
 FIX_RATIO = Path(__file__).resolve().parent / "golden" / "adversarial_windows_ratio.npz"     # tests/checks/fixup_adversarial_ratio.py (round 6)
+FIX_GPU_RATIO = Path(__file__).resolve().parent / "golden" / "adversarial_windows_gpu_ratio.npz"     # tests/checks/adversarial_gpu_ratio.py (round 6)
+GAIN = 1.73          # the factor the global delta keeps over the worst deviation any search has produced
+
+
+def k_needed(w, blob, abs_term):
+    """The k this window needs for thr = k * 2^-24 * S1 + abs to stay GAIN x above its deviation (oracle/adversarial.c)."""
+    from test_refbytes_model import EPS
+    v_ref, v_gpu, s1 = oracle.adv_point_local(w, blob)
+    return max(GAIN * abs(v_gpu - v_ref) - abs_term, 0.0) / (EPS * s1), (v_ref, v_gpu, s1)
 
 
 @pytest.mark.skipif(not FIX_RATIO.exists(), reason="fixture not generated")
-def test_ratio_windows_keep_a_factor_below_the_per_pixel_threshold(weights_blob):
-    """Round 6 flags against a PER-PIXEL threshold k * 2^-24 * S1 + abs (capped at delta), so the attack has to be on the ratio
-    kappa = (|v_gpu - v_ref| - abs) / (2^-24 * S1): a window may win by a large deviation or by a small local scale.  The committed
-    windows of that search (150,000 restarts, shipped model; 8,000 for each of 24 random models) reproduce their recorded ratio
-    on the one-pixel evaluator, the worst keeps the factor 1.7 below k that the global delta keeps over the worst deviation found,
-    and every window of the DEVIATION searches of rounds 4-5 stays below it as well."""
-    from test_refbytes_model import ABS_TERM, EPS, K_LOCAL
+def test_every_window_found_keeps_the_per_pixel_threshold_1_73_above_its_deviation(weights_blob):
+    """Round 6 flags against a PER-PIXEL threshold k * 2^-24 * S1 + abs (capped at delta), so the attack has to be on what that
+    threshold must cover: a window may win by a large deviation or by a small local scale.  The committed windows of that search
+    (240,000 restarts over four objectives, shipped model; 6,000 for each of 24 random models) reproduce their recorded figure on
+    the one-pixel evaluator, and for EVERY window any search has produced -- this one, the deviation searches of rounds 4-5, the
+    climb on the GPU itself -- the library's threshold stays 1.73 x above the deviation: the factor the global delta keeps."""
+    from test_refbytes_model import ABS_TERM, K_LOCAL
     fx = np.load(FIX_RATIO)
-
-    def kappa(w, blob):
-        v_ref, v_gpu, s1 = oracle.adv_point_local(w, blob)
-        return max(abs(v_gpu - v_ref) - ABS_TERM, 0.0) / (EPS * s1), (v_ref, v_gpu, s1)
-
+    assert abs(float(fx["gain"]) - GAIN) < 1e-6 and abs(float(fx["abs_term"]) - ABS_TERM) < 1e-9      # searched under the constants in use
     worst = 0.0
     for w, r, v in zip(fx["shipped_windows"], fx["shipped_kappa"], fx["shipped_vals"]):
-        k, vals = kappa(w, weights_blob)
+        k, vals = k_needed(w, weights_blob, ABS_TERM)
         assert abs(k - float(r)) < 1e-3 * max(1.0, k) and np.allclose(vals, v, rtol=1e-6)
         worst = max(worst, k)
-    assert worst > 1.0, "the search should reach what it reported (profiles/r06/fixup_adversarial_ratio.txt: 1.051)"
-    assert worst < K_LOCAL / 1.7, f"a window reaches kappa {worst:.3f} against k = {K_LOCAL}: raise kFixLocal"
-    for fn, key in ((FIX, "shipped_windows"), (FIX_GPU, "mfma_windows")):
+    assert worst > 1.4, "the search should reach what it reported (profiles/r06/fixup_adversarial_ratio.txt: 1.480)"
+    pools = [(FIX, "shipped_windows"), (FIX_GPU, "mfma_windows")] + ([(FIX_GPU_RATIO, "mfma_windows")] if FIX_GPU_RATIO.exists() else [])
+    for fn, key in pools:
         for w in np.load(fn)[key]:
-            assert kappa(w, weights_blob)[0] < K_LOCAL / 1.7
+            worst = max(worst, k_needed(w, weights_blob, ABS_TERM)[0])
+    assert worst <= K_LOCAL, f"a window needs k = {worst:.3f}, the library uses {K_LOCAL}: raise kFixLocal"
     for blob, wins, rr in zip(fx["random_blobs"], fx["random_windows"], fx["random_kappa"]):
         for w, r in zip(wins, rr):
-            k, _ = kappa(w, blob)
-            assert abs(k - float(r)) < 1e-3 * max(1.0, k) and k < K_LOCAL / 2
+            k, _ = k_needed(w, blob, ABS_TERM)
+            assert abs(k - float(r)) < 1e-3 * max(1.0, k) and k <= K_LOCAL
 
 
 @pytest.mark.skipif(not FIX_RATIO.exists(), reason="fixture not generated")
@@ -157,8 +163,9 @@ def test_local_selection_rule_on_a_plane_of_ratio_windows(weights_blob):
     r_out, r_pre = oracle.forward_y(plane, weights_blob)
     flagged = (np.abs(g_pre - np.rint(g_pre)) <= thr) & (g_pre > 0.5) & (g_pre < 255.5)
     assert np.array_equal(np.where(flagged, r_out, g_out), r_out)
-    # the centre pixels carry the searched values and the model's local scale (numpy, float64) is the evaluator's (C, float32)
-    for k, (w, v) in enumerate(zip(fx["shipped_windows"], fx["shipped_vals"])):
+    # the centre pixels carry the searched values, and no pixel of the plane -- the windows' neighbourhoods are nearly as hard as
+    # the windows -- comes closer to its own threshold than 1 / 1.73 (the global delta is capped in: below it the cap binds)
+    for k, v in enumerate(fx["shipped_vals"]):
         assert g_pre[cy[k], cx[k]] == np.float32(v[1]) and r_pre[cy[k], cx[k]] == np.float32(v[0])
     live = (g_pre > 0.5) & (g_pre < 255.5)
-    assert (np.abs(g_pre.astype(np.float64) - r_pre) / thr)[live].max() < 1 / 1.7
+    assert (np.abs(g_pre.astype(np.float64) - r_pre) / thr)[live].max() <= 1 / GAIN + 1e-9

@@ -300,3 +300,42 @@ def test_a_chain_reads_complete_planes(ctx, weights_blob):
         ctx.flush()
         ctx.synchronize()
         assert np.array_equal(d_out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("w,h,n_lanes", [(576, 576, 2), (1280, 720, 2), (1920, 1080, 3), (300, 70, 2)])
+def test_planes_of_a_stream_on_lanes_equal_plane_by_plane(weights_blob, w, h, n_lanes):
+    """srcnn_forward_y_lanes_dev (round 6): nine different planes alternately on two or three contexts of the one GPU, each a lane
+    with its own stream and its own deferred seam work -- every plane equals the CPU model of the kernels, the call returns with
+    everything queued and flushed (a synchronize per context is all the caller owes), and the lanes' contexts come back with their
+    own deferral setting untouched."""
+    import torch
+    n = 9
+    frames = synth_batch(w, h, n, first_frame=60)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = torch.zeros_like(d_in)
+    ctxs = [S.Context(0) for _ in range(n_lanes)]
+    streams = [torch.cuda.Stream() for _ in range(n_lanes)]
+    try:
+        for c, st in zip(ctxs, streams):
+            c.set_weights_blob(weights_blob)
+            c.set_stream(st.cuda_stream)
+        torch.cuda.synchronize()
+        for _ in range(2):
+            S.forward_y_lanes_dev(ctxs, [d_in[k].data_ptr() for k in range(n)], w, [d_out[k].data_ptr() for k in range(n)], w, w, h)
+        for c in ctxs:
+            c.synchronize()
+        got = d_out.cpu().numpy()
+        for k in range(n):
+            assert np.array_equal(got[k], oracle.gpuorder_forward_y(frames[k], weights_blob)[0]), k
+        # deferral was the call's own business: a plain launch afterwards is complete after a synchronize of the stream alone
+        one = torch.zeros_like(d_in[0])
+        ctxs[0].forward_y_dev(d_in[4].data_ptr(), w, 0, one.data_ptr(), w, 0, w, h, 1)
+        streams[0].synchronize()
+        assert np.array_equal(one.cpu().numpy(), got[4])
+        with pytest.raises(S.SrcnnError):
+            S.forward_y_lanes_dev([ctxs[0], ctxs[0]], [d_in[0].data_ptr()], w, [d_out[0].data_ptr()], w, w, h)      # the same context twice
+        with pytest.raises(S.SrcnnError):
+            S.forward_y_lanes_dev(ctxs, [d_in[0].data_ptr(), 0], w, [d_out[0].data_ptr(), d_out[1].data_ptr()], w, w, h)    # a null plane
+    finally:
+        for c in ctxs:
+            c.close()

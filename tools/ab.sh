@@ -4,7 +4,7 @@
 # Prints kernel ms per step, fraction of the f32-MFMA peak and the output crc32, alternating the two builds REPS times.
 V=$1; shift
 REPS=${REPS:-3}
-kms() { python bench.py --no-cpu-baseline --no-e2e --no-refbytes "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['output_crc32'][0])"; }
+kms() { python bench.py --no-cpu-baseline --no-e2e --no-refbytes --no-lanes "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['output_crc32'][0])"; }
 for i in $(seq $REPS); do
   echo -n "product: "; kms --steps 50 "$@"
   echo -n "$V: "; kms --lib $(pwd)/srcnn_cpp_amd/libsrcnn_amd_$V.so --steps 50 "$@"

@@ -6,7 +6,7 @@ python -m pytest tests/test_gpu_deferral.py -x -q -m gpu 2>&1 | tail -6
 for sz in "3840 2160" "1920 1080" "7680 4320" "576 576"; do set -- $sz
  for i in 1 2; do
   for d in on off; do
-   echo -n "$1x$2 deferral $d: "; python bench.py --no-cpu-baseline --no-e2e --no-refbytes --sustained-s 0 --seam-deferral $d --width $1 --height $2 --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['output_crc32'])"
+   echo -n "$1x$2 deferral $d: "; python bench.py --no-cpu-baseline --no-e2e --no-refbytes --no-lanes --sustained-s 0 --seam-deferral $d --width $1 --height $2 --steps 40 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['config']['output_crc32'])"
   done
  done
 done

@@ -18,7 +18,7 @@ for lib in product other; do
   for sz in "3840 2160" "1920 1080"; do set -- $sz
     D=gpurun_out/trace_refbytes_${lib}_$1
     ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$D -o trace -- \
-        python3 $ROOT/bench.py --mode refbytes --fix-margin 4 $L --width $1 --height $2 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes ) > $D.log 2>&1
+        python3 $ROOT/bench.py --mode refbytes --fix-margin 4 $L --width $1 --height $2 --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes --no-lanes ) > $D.log 2>&1
     echo "# rocprofv3 --kernel-trace --stats, bench.py --mode refbytes --fix-margin 4 $L $1x$2" >> $OUT
     grep -h "srcnn" $D/*kernel_stats.csv 2>/dev/null | grep -v probe | cut -d, -f1-4 >> $OUT
     find $D -name "*kernel_trace.csv" -size +2M -delete

@@ -3,7 +3,7 @@
 #   tools/ab_s16.sh NAME [NAME ...]     ms per step and output crc32 in SPLIT16 and REFBYTES16, alternating, REPS times
 export TMPDIR=/tmp
 REPS=${REPS:-3}
-kms() { python bench.py --no-cpu-baseline --no-e2e --no-refbytes --sustained-s 0 --steps 50 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['config']['output_crc32'][0])"; }
+kms() { python bench.py --no-cpu-baseline --no-e2e --no-refbytes --no-lanes --sustained-s 0 --steps 50 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['config']['output_crc32'][0])"; }
 for mode in split16 refbytes16; do
   for i in $(seq $REPS); do
     echo -n "$mode product: "; kms --mode $mode

@@ -7,7 +7,7 @@
 # 3. PMC passes (one counter group per run, never together with a trace), for the float32 MFMA mode and
 # for the opt-in split-f16 mode, 4. the other configurations (tools/measure_all.sh), 5. in-kernel stamps.
 # tools/pmc_summarize.py turns the PMC csv files into profiles/rNN/*_pmc_summary.json.
-# (the profiled command lines carry --no-e2e --no-refbytes: only the K steps of the headline workload run under the profiler,
+# (the profiled command lines carry --no-e2e --no-refbytes --no-lanes: only the K steps of the headline workload run under the profiler,
 # so no dispatch of the host-frame pipeline or of the REFBYTES leg is averaged into the per-kernel figures)
 OUT=${1:-gpurun_out/prof}
 ROOT=$(pwd)
@@ -25,13 +25,13 @@ python bench.py --mode split16 --frames 64 --steps 10 --no-cpu-baseline > $OUT/b
 fi
 for mode in mfma split16; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$mode -o trace -- \
-      python3 $ROOT/bench.py --mode $mode --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/trace_$mode.log 2>&1
+      python3 $ROOT/bench.py --mode $mode --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes --no-lanes ) > $OUT/trace_$mode.log 2>&1
   for grp in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY"; do
     tag=$(echo $grp | cut -d' ' -f1)
     ( cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pmc_${mode}_$tag -o pmc -- \
-        python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/pmc_${mode}_$tag.log 2>&1
+        python3 $ROOT/bench.py --mode $mode --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes --no-lanes ) > $OUT/pmc_${mode}_$tag.log 2>&1
   done
 done
 # the kernels beside the headline: the REFBYTES step (flag-writing strip kernel, fix_collect, fix_apply, idle
@@ -43,10 +43,10 @@ for run in "refbytes --mode refbytes" "pipeline --path pipeline"; do
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
     g=$(echo $grp | cut -d' ' -f1)
     ( cd /tmp && rocprofv3 --pmc $grp --output-format csv -d $ROOT/$OUT/pmc_${tag}_$g -o pmc -- \
-        python3 $ROOT/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/pmc_${tag}_$g.log 2>&1
+        python3 $ROOT/bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-refbytes --no-lanes ) > $OUT/pmc_${tag}_$g.log 2>&1
   done
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_$tag -o trace -- \
-      python3 $ROOT/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes ) > $OUT/trace_$tag.log 2>&1
+      python3 $ROOT/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline --no-e2e --no-refbytes --no-lanes ) > $OUT/trace_$tag.log 2>&1
 done
 # ... and a kernel trace of ONE unfused 3840x2160 frame, the run the pmc_unfused_* passes below count (TB/s from the counters)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/trace_unfused1 -o trace -- \
