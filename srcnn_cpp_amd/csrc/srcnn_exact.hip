@@ -791,6 +791,9 @@ __device__ __forceinline__ void fix_kernel_body(const FixParams &p)
         const unsigned scat_cap = region_wgs * (FIX_SEG_TILES * (FIX_DENSE_MIN - 1)), dense_cap = region_wgs * FIX_SEG_TILES;
         for (bool first_round = true;; first_round = false) {
             __syncthreads();                         // s_item's readers of the previous round are done (and the kernel's LDS set-up)
+            // (round 6 A/B, not kept -- profiles/r06/fix_apply_ab.txt: a first item spread over the compute units instead of the block's
+            // own index, no draw when the items fit the grid, a static assignment b, b + G, ...: all within noise at every size, the
+            // static form 10 % slower on a 7680x4320 plane)
             if (tid == 0) s_item = first_round ? blockIdx.x : gridDim.x + atomicAdd(fix_word(p.counters, FIX_NEXT_ITEM), 1u);
             __syncthreads();
             const unsigned item = s_item;

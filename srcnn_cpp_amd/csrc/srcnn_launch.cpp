@@ -354,8 +354,14 @@ int run_strip(srcnn_ctx *c, int mode, StripParams p, int n_frames, int fix_frame
         // the fix-up batch in the reference's arithmetic (no threshold involved).  No host read: the stream is never stalled.
         static const char *env_rerun = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FORCE_RERUN");     // test knob: every launch is redone
         f.rerun_above = (env_rerun && std::atoi(env_rerun)) ? -1.f : c->fix_strict ? 0.5f : INFINITY;
-        static const char *env_lds = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FIX_LDS");           // A/B knob: 0 = the scalar-load fix_apply of rounds 3-5
-        HIP_TRY(c, launch_fixup(f, c->n_cu, c->fix_strict, !(env_lds && std::atoi(env_lds) == 0), c->stream));
+        // fix_apply with both weight tables in LDS (3 workgroups per CU) on planes whose items fit ONE round of the draw: an item
+        // alone on a compute unit is bound by its scalar weight loads (L2 round trips the scalar cache cannot hold back), which five
+        // co-resident workgroups hide and a few hundred items do not -- 1920x1080: fix-up +64 -> +54 us, 1280x720 +52 -> +43; from
+        // ~2.4 MPix on the scalar-load form's higher occupancy wins (3840x2160: +124 against +141 us).  profiles/r06/fix_apply_ab.txt
+        static const char *env_lds = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FIX_LDS");           // A/B knob: 0 / 1 = never / always
+        const bool lds_weights = env_lds ? std::atoi(env_lds) == 1
+                                         : (long)p.width * (p.row_end - p.row_begin) * fix_frames <= 2400000L;
+        HIP_TRY(c, launch_fixup(f, c->n_cu, c->fix_strict, lds_weights, c->stream));
     }
     return SRCNN_OK;
 }

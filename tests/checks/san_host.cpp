@@ -22,7 +22,7 @@ hipError_t launch_strip(int, const StripParams &, int, hipStream_t, size_t) { re
 hipError_t launch_strip_fold(const StripParams &, const FoldParams &, hipStream_t, size_t) { return never(); }
 hipError_t launch_strip_safe(int, const StripParams &, int, hipStream_t, size_t) { return never(); }
 long interlock_probe_mismatches(int, hipStream_t) { return 0; }
-hipError_t launch_fixup(const FixParams &, int, bool, hipStream_t) { return never(); }
+hipError_t launch_fixup(const FixParams &, int, bool, bool, hipStream_t) { return never(); }
 size_t fixup_list_entries(int, int, int, size_t *dense) { if (dense) *dense = 0; return 0; }
 hipError_t launch_split16(const StripParams &, int, hipStream_t, size_t) { return never(); }
 hipError_t launch_conv99_exact(const uint8_t *, long, float *, long, int, int, const float *, float, hipStream_t) { return never(); }

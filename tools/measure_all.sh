@@ -17,7 +17,11 @@ run --steps 3 --path host --width 5760 --height 3240 --frames 64 # ... 64 of the
 run --steps 10 --path host                                      # PCIe-inclusive host-buffer entry point
 run --steps 3 --warmup 1 --path surface                         # the reference call surface on host buffers (32 f32 planes over PCIe)
 run --steps 10 --path surface-dev                              # the same two call sites with the 32 planes kept on the device (DevicePlane<float>)
-run --steps 20 --width 1920 --height 1080                       # a 1080p plane
+run --steps 20 --width 1920 --height 1080                       # a 1080p plane (the line's `two_lanes`: the same planes alternately on two contexts of the GPU)
+run --steps 20 --width 1280 --height 720                        # small planes: where two lanes pay (`two_lanes`)
+run --steps 20 --width 960 --height 540
+run --steps 20 --width 2560 --height 1440
+run --steps 20 --mode refbytes --width 1280 --height 720
 run --steps 20 --path pipeline                                  # BGR 1080p -> BGR 4K on device (8f rows + conv path)
 run --steps 5 --mode exact                                      # bit-exact VALU mode
 run --steps 30 --mode refbytes                                  # the reference's bytes: MFMA kernel + exact fix-up of flagged pixels

@@ -78,7 +78,8 @@ tools/ab_refbytes.sh $OUT/fix_apply_ab_final.txt > /dev/null 2>&1
 tools/ab_defer.sh > $OUT/seam_deferral_ab_final.txt 2>&1
 python tests/checks/soak.py 120 31 > $OUT/soak.txt 2>&1
 python tests/checks/soak_paths.py 60 37 > $OUT/soak_paths.txt 2>&1
-python tests/checks/soak_models.py 240 3 > $OUT/soak_models.txt 2>&1
+python tests/checks/soak_models.py 300 3 > $OUT/soak_models.txt 2>&1
+python tools/two_lane_probe.py 3840x2160,2560x1440,1920x1080,1280x720,960x540,576x576,7680x540 > $OUT/two_lane_probe.txt 2>&1
 python tests/checks/parity_stats.py > $OUT/parity_stats_4k.txt 2>&1
 python tests/checks/split16_stats.py > $OUT/parity_stats_split16_4k.txt 2>&1
 [ -x build/f16_probe ] && ./build/f16_probe > $OUT/f16_probe.txt 2>&1
