@@ -129,6 +129,10 @@ int srcnn_flush(srcnn_ctx *ctx);
  * hazard-safe one (every wait state the ISA manual asks for, ~3 % slower, the same bytes), chosen when that check fails;
  * srcnn_last_error() then says so. */
 int srcnn_kernel_variant(const srcnn_ctx *ctx);
+/* Pin the form: 1 = the hazard-safe kernels whatever the probe said -- for a deployment that will not rest on a measured,
+ * undocumented interlock: every wait state the ISA manual asks for is in the code the compiler emits, the bytes are the same, the
+ * fused pass is ~3 % slower and seam deferral is not used; 0 = back to what the probe allows (the fast form only where it passed). */
+int srcnn_set_kernel_variant(srcnn_ctx *ctx, int variant);
 
 /* ---- the reference call surface, host buffers ----------------------------- */
 

@@ -138,6 +138,7 @@ def load_library() -> C.CDLL:
         "srcnn_set_seam_deferral": ([vp, i], i),
         "srcnn_flush": ([vp], i),
         "srcnn_set_fixup_margin": ([vp, C.c_float], i),
+        "srcnn_set_kernel_variant": ([vp, i], i),
         "srcnn_set_fixup_local": ([vp, C.c_float], i),
         "srcnn_fixup_local_stats": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i),
         "srcnn_scaled_size": ([i, i, C.c_float, C.POINTER(i), C.POINTER(i)], i),
@@ -163,7 +164,7 @@ def load_library() -> C.CDLL:
 
 ABI_SYMBOLS = (
     "srcnn_abi_version", "srcnn_create", "srcnn_destroy", "srcnn_last_error", "srcnn_set_mode",
-    "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_kernel_variant", "srcnn_conv99", "srcnn_conv11",
+    "srcnn_get_mode", "srcnn_set_stream", "srcnn_synchronize", "srcnn_kernel_variant", "srcnn_set_kernel_variant", "srcnn_conv99", "srcnn_conv11",
     "srcnn_conv55", "srcnn_conv99x11", "srcnn_set_weights", "srcnn_forward_y", "srcnn_forward_y_frames",
     "srcnn_forward_y_dev",
     "srcnn_forward_y_rows_dev", "srcnn_forward_y_rows_halo_dev", "srcnn_halo_transport", "srcnn_forward_y_unfused_dev", "srcnn_conv99x11_dev",
@@ -278,6 +279,10 @@ class Context:
     def kernel_variant(self) -> int:
         """0 = fast strip kernels (hardware interlock verified at create), 1 = hazard-safe kernels (srcnn_kernel_variant)."""
         return int(self._lib.srcnn_kernel_variant(self._h))
+
+    def set_kernel_variant(self, variant: int):
+        """1 = pin the hazard-safe strip kernels (same bytes, ~3 % slower), 0 = what the interlock probe allows (srcnn_set_kernel_variant)."""
+        self._check(self._lib.srcnn_set_kernel_variant(self._h, int(variant)))
 
     def set_weights(self, w1, b1, w2, b2, w3, b3):
         w1, b1 = _wt(w1, 5184, "kernel99"), _wt(b1, 64, "bias99")

@@ -55,6 +55,19 @@ void release(DevBuf &b)
 }  // namespace host
 }  // namespace srcnn
 
+// The interlock probe's verdict for a device (0 = the hardware interlocks the fast row body's dependencies), run once per device
+// and process.
+static long probe_verdict(int device, int n_devices, hipStream_t stream)
+{
+    static std::mutex probe_mutex;
+    static std::vector<long> probe_result;          // per device: -2 = not run yet
+    std::lock_guard<std::mutex> lk(probe_mutex);
+    if ((int)probe_result.size() < n_devices) probe_result.resize((size_t)n_devices, -2);
+    if (device < 0 || device >= (int)probe_result.size()) return -1;
+    if (probe_result[(size_t)device] == -2) probe_result[(size_t)device] = srcnn::interlock_probe_mismatches(device, stream);
+    return probe_result[(size_t)device];
+}
+
 extern "C" {
 
 int srcnn_abi_version(void) { return 1; }
@@ -80,15 +93,7 @@ int srcnn_create(srcnn_ctx **out, int device)
     c->stream = c->own_stream;
     // The fast strip kernels rely on the hardware interlocking three inline-asm MFMA <-> vector-ALU dependencies (srcnn_probe.hip):
     // checked once per device and process; a device that does not gets the hazard-safe kernels -- same bytes, ~3 % slower.
-    static std::mutex probe_mutex;
-    static std::vector<long> probe_result;          // per device: -2 = not run yet
-    long bad;
-    {
-        std::lock_guard<std::mutex> lk(probe_mutex);
-        if ((int)probe_result.size() < n) probe_result.resize((size_t)n, -2);
-        if (probe_result[(size_t)device] == -2) probe_result[(size_t)device] = interlock_probe_mismatches(device, c->own_stream);
-        bad = probe_result[(size_t)device];
-    }
+    long bad = probe_verdict(device, n, c->own_stream);
     const char *force = SRCNN_DEBUG_ENV("SRCNN_DEBUG_FORCE_SAFE");      // test knob: behave as if the probe had failed
     if (force && std::atoi(force)) bad = 1;
     if (bad != 0) {
@@ -101,6 +106,20 @@ int srcnn_create(srcnn_ctx **out, int device)
 }
 
 int srcnn_kernel_variant(const srcnn_ctx *c) { return c ? (c->safe_hazards ? 1 : 0) : SRCNN_ERR_INVALID; }
+
+int srcnn_set_kernel_variant(srcnn_ctx *c, int variant)
+{
+    BIND(c);
+    if (variant != 0 && variant != 1) return fail(c, SRCNN_ERR_INVALID, "set_kernel_variant: 0 (what the interlock probe allows) or 1 (hazard-safe)");
+    if (variant == 1) {
+        c->safe_hazards = true;
+        return SRCNN_OK;
+    }
+    int n = 0;
+    HIP_TRY(c, hipGetDeviceCount(&n));
+    c->safe_hazards = probe_verdict(c->device, n, c->own_stream) != 0;      // the fast form only where the probe found it safe
+    return SRCNN_OK;
+}
 
 void srcnn_destroy(srcnn_ctx *c)
 {

@@ -254,6 +254,35 @@ def test_safe_hazard_kernels_give_the_same_bytes(weights_blob):
     assert "hazard-safe" in " ".join(msg)
 
 
+def test_a_deployment_can_pin_the_safe_kernels(weights_blob):
+    """srcnn_set_kernel_variant (round 6): the PRODUCT library lets a cautious deployment pin the hazard-safe
+    strip kernels without any probe failing -- same bytes on a plane with work items, seams and the FAST body, with and without
+    REFBYTES; deferral is not used in that form; 0 goes back to what the probe allows."""
+    import torch
+    y = synth_luma(1920, 400, frame=2)
+    with S.Context(0) as ctx:
+        ctx.set_weights_blob(weights_blob)
+        assert ctx.kernel_variant() == 0
+        fast = ctx.forward_y(y)
+        ctx.set_kernel_variant(1)
+        assert ctx.kernel_variant() == 1
+        assert np.array_equal(ctx.forward_y(y), fast)
+        ctx.set_seam_deferral(True)                      # asked for, not used by the safe form: the plane is complete after the stream
+        d_in, d_out = torch.from_numpy(y).cuda(), torch.zeros((400, 1920), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.forward_y_dev(d_in.data_ptr(), 1920, 0, d_out.data_ptr(), 1920, 0, 1920, 400, 1)
+        ctx.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), fast)
+        ctx.set_seam_deferral(False)
+        ctx.set_mode(S.MODE_REFBYTES)
+        assert np.array_equal(ctx.forward_y(y), oracle.forward_y(y, weights_blob)[0])
+        ctx.set_mode(S.MODE_MFMA)
+        ctx.set_kernel_variant(0)
+        assert ctx.kernel_variant() == 0 and np.array_equal(ctx.forward_y(y), fast)
+        with pytest.raises(S.SrcnnError):
+            ctx.set_kernel_variant(2)
+
+
 def test_error_paths_of_the_round3_entry_points(weights_blob):
     w1, b1, w2, b2, w3, b3 = S.split_weights(weights_blob)
     y = synth_luma(64, 32)
