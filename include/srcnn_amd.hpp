@@ -100,6 +100,8 @@ public:
     void flush() { check(srcnn_flush(get())); }
     // 0: the fast strip kernels (their hardware interlock was verified on this device at creation), 1: the hazard-safe ones
     int kernel_variant() const { return srcnn_kernel_variant(get()); }
+    // A cautious deployment pins the hazard-safe kernels (same bytes, ~3 % slower): srcnn_set_kernel_variant
+    void pin_safe_kernels(bool on = true) { check(srcnn_set_kernel_variant(get(), on ? 1 : 0)); }
 
 private:
     struct Handle {
