@@ -470,3 +470,39 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=str(Path(__file__).resolve().parent.parent))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_both_forms_of_fix_apply_give_the_reference_bytes(weights_blob):
+    """Round 6: fix_apply_kernel exists twice -- weights through scalar loads (5 workgroups per CU; planes above 2.4 MPix) and both
+    weight tables in LDS (3 per CU; small planes, whose items are one round of the draw).  The library picks by plane size; the
+    tuning build's SRCNN_DEBUG_FIX_LDS forces either form: a textured plane, a letterboxed one (dense tiles) and a batch of three
+    frames come out as the reference's bytes both ways, with the same statistics."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import json, numpy as np, oracle, srcnn_cpp_amd as S
+from srcnn_cpp_amd.synth import synth_batch, synth_luma
+S.use_library(S.tuning_library_path())
+blob = S.load_weights()
+out = {}
+with S.Context(0) as ctx:
+    ctx.set_weights_blob(blob)
+    ctx.set_mode(S.MODE_REFBYTES)
+    y = synth_luma(1000, 333, frame=4)
+    box = np.concatenate([np.full((48, 700), 38, np.uint8), synth_luma(700, 200, frame=2), np.full((48, 700), 38, np.uint8)])
+    for name, p in (("textured", y), ("letterbox", box)):
+        assert np.array_equal(ctx.forward_y(p), oracle.forward_y(p, blob)[0]), name
+    frames = synth_batch(640, 360, 3, first_frame=7)
+    got = ctx.forward_y_frames(frames)
+    assert all(np.array_equal(got[k], oracle.forward_y(frames[k], blob)[0]) for k in range(3))
+    st = ctx.fixup_stats()
+    print(json.dumps({k: st[k] for k in ("scattered_pixels", "dense_tiles", "bytes_changed", "exact_reruns")}))
+"""
+    stats = []
+    for lds in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SRCNN_DEBUG_FIX_LDS=lds), capture_output=True, text=True,
+                           timeout=600, cwd=str(Path(__file__).resolve().parent.parent))
+        assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+        stats.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert stats[0] == stats[1] and stats[0]["dense_tiles"] > 0 and stats[0]["scattered_pixels"] > 0 and stats[0]["exact_reruns"] == 0
