@@ -929,7 +929,7 @@ def worker(args):
                                                                    (round(v, 4) for v in ctx.fixup_local_stats()))),
                                    # |v - r| / thr of the worst window any search has produced (not measured in this run): the searches
                                    # climb on the k that keeps thr 1.73 x above the deviation and ask for 1.480 (CPU, 241 M evaluations;
-                                   # GPU 1.480), the library uses 1.55 (abs 2.44e-4): 0.55 of thr -- profiles/r06/fixup_adversarial_ratio.txt; the
+                                   # GPU 1.480), a longer GPU climb 1.525), the library uses 1.6 (abs 2.44e-4): 0.55 of thr -- profiles/r06/fixup_adversarial_ratio.txt; the
                                    # worst of all is a window of LARGE local scale, where the cap delta binds: 7.93e-4 / 1.376e-3 (round 5's GPU search)
                                    "largest_deviation_any_search_found_over_threshold": 0.577,
                                    "equals_reference_arithmetic": equal,
@@ -949,7 +949,7 @@ def worker(args):
                                      "threshold_factor": round(4.0 * 8.0 / 6.0, 3), "device_side_net": True, "fixup": ctx.fixup_stats(),
                                      "per_pixel_threshold": dict(zip(("k", "largest_deviation_over_own_threshold_this_run"),
                                                                      (round(v, 4) for v in ctx.fixup_local_stats()))),
-                                     # the GPU-side climb asks for k = 2.023 at 1.73 x, the library uses 2.1 (profiles/r06/adversarial_gpu_ratio.txt);
+                                     # the GPU-side climbs ask for k = 2.023 at 1.73 x, the library uses 2.15 (profiles/r06/adversarial_gpu_ratio.txt);
                                      # where the cap binds: 1.13e-3 / 1.835e-3 (profiles/r05/adversarial_gpu.txt)
                                      "largest_deviation_any_search_found_over_threshold": 0.616,
                                      "equals_reference_arithmetic": equal16,

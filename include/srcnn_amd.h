@@ -410,8 +410,8 @@ int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
  * the strip kernels flag pixel x against
  *     thr(x) = min(delta, margin * k_local * 2^-24 * S1(x) + abs_local),        abs_local = 16 * 2^-24 * 256 = 2.44e-4,
  * S1(x) = the sum over the pixel's 5 x 5 feature window of sum_c max_tap|W3[c][tap]| * F_c -- carried through the kernels in five
- * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.3875 (k = 1.55 with the default margin 4;
- * REFBYTES16: k = 2.1, its kernel's noise is wider): thr stays 1.73 x above the deviation of EVERY window the adversarial
+ * otherwise unused rows of the layer-3 MFMAs, no extra MFMA.  Default k_local = 0.4 (k = 1.6 with the default margin 4;
+ * REFBYTES16: k = 2.15, its kernel's noise is wider): thr stays 1.73 x above the deviation of EVERY window the adversarial
  * searches have produced -- the factor the global delta keeps over the worst of them; the searches climb on exactly that
  * quantity, on the CPU models and on the kernels themselves (profiles/r06/fixup_adversarial_ratio.txt, adversarial_gpu_ratio.txt) --
  * and content stays below 0.4 thr (fixup_local_scale.txt).  0.57-0.65 x the flagged pixels on ordinary content (0.27 x on sparse

@@ -239,7 +239,7 @@ int srcnn_set_fixup_local(srcnn_ctx *c, float k_local)
 {
     BIND(c);
     if (!(k_local >= 0.f && k_local <= 64.f)) return fail(c, SRCNN_ERR_INVALID, "set_fixup_local: the factor must lie in [0, 64]");
-    // one knob for both byte-exact modes: REFBYTES16 keeps its own factor's ratio to REFBYTES' (2.1 / 1.55)
+    // one knob for both byte-exact modes: REFBYTES16 keeps its own factor's ratio to REFBYTES' (2.15 / 1.6)
     c->fix_local = k_local;
     c->fix_local16 = k_local * (kFixLocal16 / kFixLocal);
     return SRCNN_OK;

@@ -109,7 +109,7 @@ for a in ABS_CANDIDATES:
     print(f"  abs {a:.3e}: k >= {k:.3f}")
 
 # what a (k, abs) pair flags: the mean threshold over the live pixels of a class against the global delta (flagged fraction ~ 2 x mean threshold)
-K_ABS = [(float(sys.argv[2]), float(sys.argv[3]))] if len(sys.argv) > 3 else [(2.4, 4 * EPS * 256), (1.8, 8 * EPS * 256), (1.55, 16 * EPS * 256)]
+K_ABS = [(float(sys.argv[2]), float(sys.argv[3]))] if len(sys.argv) > 3 else [(2.4, 4 * EPS * 256), (1.8, 8 * EPS * 256), (1.6, 16 * EPS * 256)]
 for k, a in K_ABS:
     print(f"\nthr = min(delta, {k} * 2^-24 * S1 + {a:.3e}):  mean threshold / delta per class (= flagged pixels against the global threshold's)")
     for name, lv, d, s1 in rows:

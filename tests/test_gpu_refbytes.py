@@ -89,19 +89,19 @@ def test_full_4k_frame_has_the_oracle_sha(ref_ctx, weights_blob):
         assert changed == pin["u8_mismatches_between_them"]     # exactly the bytes the MFMA mode differs on
         assert abs(st["delta"] - 1.376e-3) < 2e-5
         k, ratio = ref_ctx.fixup_local_stats()
-        assert abs(k - 1.55) < 1e-3 and 0 < ratio < 0.5, (k, ratio)      # no deviation above half its own pixel's threshold
+        assert abs(k - 1.6) < 1e-3 and 0 < ratio < 0.5, (k, ratio)      # no deviation above half its own pixel's threshold
         # ... and against the one global threshold of rounds 3-5 (srcnn_set_fixup_local(ctx, 0)): same bytes, ~2 x the pixels
         ref_ctx.set_fixup_local(0.0)
         out0 = ref_ctx.forward_y(y)
         st0 = ref_ctx.fixup_stats()
-        ref_ctx.set_fixup_local(0.3875)
+        ref_ctx.set_fixup_local(0.4)
         assert np.array_equal(out0, out)
         flagged0 = st0["scattered_pixels"] - st["scattered_pixels"]
         assert 0.002 * y.size < flagged0 < 0.008 * y.size and flagged < 0.62 * flagged0, (flagged, flagged0)
     else:
         assert 0.0015 * y.size < flagged < 0.005 * y.size
         assert 200 <= changed <= 450 and abs(st["delta"] - 1.834e-3) < 2e-5
-        assert abs(ref_ctx.fixup_local_stats()[0] - 2.1) < 1e-3      # the split-f16 kernel's own factor (its noise is wider)
+        assert abs(ref_ctx.fixup_local_stats()[0] - 2.15) < 1e-3      # the split-f16 kernel's own factor (its noise is wider)
     assert 0 < st["max_dev"] < 0.5 * st["delta"], st            # the margin: |v_fast - v_ref| seen on the flagged sample
 
 

@@ -22,7 +22,7 @@ def shipped_delta(blob, margin=4.0):
     return margin * 2.0 ** -24 * np.sqrt((w3 ** 2).sum()) * m2 + 4.0 * 2.0 ** -24 * 256.0
 
 
-K_LOCAL, ABS_TERM, EPS = 4.0 * 0.3875, 16.0 * 2.0 ** -24 * 256.0, 2.0 ** -24      # srcnn_ctx.h: kFixMargin * kFixLocal, kFixAbsLocal
+K_LOCAL, ABS_TERM, EPS = 4.0 * 0.4, 16.0 * 2.0 ** -24 * 256.0, 2.0 ** -24      # srcnn_ctx.h: kFixMargin * kFixLocal, kFixAbsLocal
 
 
 def local_threshold(y, blob, delta, k=K_LOCAL):

@@ -20,7 +20,7 @@ ap.add_argument("--sizes", default="3840x2160,1920x1080,7680x4320")
 ap.add_argument("--margins", default="4,6")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--modes", default="refbytes")
-ap.add_argument("--locals", default="0.3875,0", help="per-pixel threshold factors to time (srcnn_set_fixup_local; 0 = the global threshold only)")
+ap.add_argument("--locals", default="0.4,0", help="per-pixel threshold factors to time (srcnn_set_fixup_local; 0 = the global threshold only)")
 args = ap.parse_args()
 if args.lib:
     S.use_library(args.lib)
