@@ -87,7 +87,7 @@ def test_locally_flagged_pixels_are_all_that_can_differ(weights_blob, name, y):
         assert (np.abs(g_pre.astype(np.float64) - r_pre) / thr)[live].max() < 0.5
     if name in ("synthetic", "white noise"):
         glob = (np.abs(g_pre - np.rint(g_pre)) <= delta) & live
-        assert thr[live].mean() < 0.6 * delta and flagged.sum() < 0.75 * glob.sum()     # (small planes: the counts are noisy)
+        assert thr[live].mean() < 0.66 * delta and flagged.sum() < 0.8 * glob.sum()      # (small planes: the counts are noisy)
 
 
 def test_model_with_small_weights_and_a_large_bias():
