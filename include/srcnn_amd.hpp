@@ -301,6 +301,10 @@ public:
     SessionSet &operator=(const SessionSet &) = delete;
     int size() const { return (int)ctxs_.size(); }
     srcnn_ctx *const *data() const { return ctxs_.data(); }
+    void synchronize() const
+    {
+        for (srcnn_ctx *c : ctxs_) check(srcnn_synchronize(c));
+    }
     void set_weights(const float kernel99[64][9][9], const float bias99[64], const float kernel11[32][64],
                      const float bias11[32], const float kernel55[32][5][5], float bias55)
     {
@@ -347,6 +351,28 @@ inline void ForwardYFrames(SessionSet &set, std::vector<MatU8> &src, std::vector
     }
     set.check(srcnn_forward_y_frames_multi(set.data(), set.size(), in.data(), detail::stride<std::uint8_t>(src[0]), out.data(),
                                            detail::stride<std::uint8_t>(dst[0]), src[0].cols, src[0].rows, (int)src.size()));
+}
+
+// DEVICE-resident planes of a stream (DevicePlane<unsigned char>: `data` a device address on the GPU of the session that will
+// run it) alternately on the sessions of the set, used as LANES: plane f on session f mod size().  `SessionSet lanes({0, 0})` is
+// two lanes of GPU 0 -- the next plane's kernel fills the compute units the previous plane's slowest workgroups leave idle:
+// what small planes lose most (576x576: 0.60 -> 0.75 of the f32 MFMA peak).  Asynchronous: synchronize() the set to wait.
+template <class PlaneU8>
+inline void ForwardYLanes(SessionSet &set, std::vector<PlaneU8> &d_src, std::vector<PlaneU8> &d_dst)
+{
+    if (d_src.empty() || d_src.size() != d_dst.size()) throw Error(SRCNN_ERR_INVALID, "ForwardYLanes: need as many outputs as inputs");
+    std::vector<const std::uint8_t *> in(d_src.size());
+    std::vector<std::uint8_t *> out(d_src.size());
+    for (std::size_t i = 0; i < d_src.size(); ++i) {
+        if (d_src[i].rows != d_src[0].rows || d_src[i].cols != d_src[0].cols || d_dst[i].rows != d_src[0].rows || d_dst[i].cols != d_src[0].cols ||
+            detail::stride<std::uint8_t>(d_src[i]) != detail::stride<std::uint8_t>(d_src[0]) ||
+            detail::stride<std::uint8_t>(d_dst[i]) != detail::stride<std::uint8_t>(d_dst[0]))
+            throw Error(SRCNN_ERR_INVALID, "ForwardYLanes: planes must share size and row stride");
+        in[i] = detail::ptr<const std::uint8_t>(d_src[i]);
+        out[i] = detail::ptr<std::uint8_t>(d_dst[i]);
+    }
+    set.check(srcnn_forward_y_lanes_dev(set.data(), set.size(), in.data(), detail::stride<std::uint8_t>(d_src[0]), out.data(),
+                                        detail::stride<std::uint8_t>(d_dst[0]), d_src[0].cols, d_src[0].rows, (int)d_src.size()));
 }
 
 // A stream of equally sized LARGE planes, each row-striped over the GPUs of the set, pipelined: uploads, kernels and downloads

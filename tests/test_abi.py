@@ -193,6 +193,24 @@ int main() { return 0; }
                         f"-I{ROOT / 'tests' / 'helpers'}", str(src)], check=True)
 
 
+def test_lanes_adapter_compiles():
+    """srcnn::ForwardYLanes over a SessionSet (two sessions on one device = two lanes of it): compile only."""
+    import subprocess, tempfile
+    code = r'''
+#include "srcnn_amd.hpp"
+void stream(srcnn::SessionSet &lanes, std::vector<srcnn::DevicePlane<unsigned char>> &in, std::vector<srcnn::DevicePlane<unsigned char>> &out)
+{
+    srcnn::ForwardYLanes(lanes, in, out);
+    lanes.synchronize();
+}
+int main() { return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "m.cpp"
+        src.write_text(code)
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src)], check=True)
+
+
 def test_create_without_gpu_fails_loudly(lib):
     import torch
     if torch.cuda.is_available():

@@ -209,7 +209,7 @@ def test_cpp_host_with_several_contexts(tmp_path):
     res = subprocess.run([str(exe), str(S._WEIGHTS_PATH), str(w), str(h), str(n), str(out_file), "0", "0"],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr + res.stdout
-    assert "on 2 contexts" in res.stdout
+    assert "on 2 contexts" in res.stdout and "lanes ok" in res.stdout
     got = np.fromfile(out_file, np.uint8).reshape(h, w)
     m_out, _ = oracle.gpuorder_forward_y(synth_luma(w, h, frame=n - 1), S.load_weights())
     assert np.array_equal(got, m_out)

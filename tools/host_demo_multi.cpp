@@ -3,7 +3,8 @@
 //   * ONE plane row-striped over the contexts (srcnn_forward_y_striped: own rows uploaded per device, 6 halo rows
 //     per boundary device to device, interior rows first, edge bands after the copies)
 //   * a stream of frames, contiguous ranges per context (srcnn_forward_y_frames_multi, no collective)
-// and checks both bit for bit against the single-context ForwardY.
+//   * device-resident planes of a stream alternately on the contexts used as lanes (srcnn_forward_y_lanes_dev)
+// and checks all three bit for bit against the single-context ForwardY.
 // Build: g++ -std=c++17 -pthread -Iinclude tools/host_demo_multi.cpp -Lsrcnn_cpp_amd -lsrcnn_amd \
 //            -Wl,-rpath,$PWD/srcnn_cpp_amd -o build/host_demo_multi
 // Run:   build/host_demo_multi weights.f32 W H N_FRAMES out.u8 dev0 [dev1 ...]   (a device may repeat)
@@ -64,7 +65,20 @@ int main(int argc, char **argv)
         const auto t2 = std::chrono::steady_clock::now();
         for (int k = 0; k < NF; ++k)
             if (std::memcmp(out[k].data, ref[k].data, (size_t)W * H) != 0) { std::fprintf(stderr, "frame %d != single\n", k); return 5; }
-        std::printf("ok %dx%d x%d on %d contexts: striped %.3f ms, frames %.3f ms (host buffers, PCIe-inclusive)\n", W, H, NF,
+        // device-resident planes of a stream on the set's contexts used as LANES (two contexts on one GPU = two lanes of it:
+        // srcnn_forward_y_lanes_dev): upload once, queue everything, wait once, compare
+        {
+            auto d_in = srcnn::DevicePlanes<unsigned char>(NF, W, H), d_out = srcnn::DevicePlanes<unsigned char>(NF, W, H);
+            for (int k = 0; k < NF; ++k)
+                if (srcnn_dev_upload(d_in[k].ctx, d_in[k].data, in[k].data, (size_t)W * H) != SRCNN_OK) { std::fprintf(stderr, "upload\n"); return 7; }
+            srcnn::ForwardYLanes(set, d_in, d_out);
+            set.synchronize();
+            for (int k = 0; k < NF; ++k) {
+                const Plane got = d_out[k].download();
+                if (std::memcmp(got.data, ref[k].data, (size_t)W * H) != 0) { std::fprintf(stderr, "lane plane %d != single\n", k); return 7; }
+            }
+        }
+        std::printf("ok %dx%d x%d on %d contexts: striped %.3f ms, frames %.3f ms (host buffers, PCIe-inclusive); lanes ok\n", W, H, NF,
                     set.size(), std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count());
     } catch (const srcnn::Error &e) {
