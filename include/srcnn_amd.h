@@ -414,8 +414,8 @@ int srcnn_set_fixup_margin(srcnn_ctx *ctx, float factor);
  * REFBYTES16: k = 2.15, its kernel's noise is wider): thr stays 1.73 x above the deviation of EVERY window the adversarial
  * searches have produced -- the factor the global delta keeps over the worst of them; the searches climb on exactly that
  * quantity, on the CPU models and on the kernels themselves (profiles/r06/fixup_adversarial_ratio.txt, adversarial_gpu_ratio.txt) --
- * and content stays below 0.4 thr (fixup_local_scale.txt).  0.57-0.65 x the flagged pixels on ordinary content (0.27 x on sparse
- * content, 0.98 x on very bright content).  The monitor and the device-side net compare each recomputed pixel's deviation with
+ * and content stays below 0.4 thr (fixup_local_scale.txt).  0.60-0.70 x the flagged pixels on ordinary content (0.31 x on sparse
+ * content, 0.99 x on very bright content).  The monitor and the device-side net compare each recomputed pixel's deviation with
  * ITS threshold (rerun above 1/2).  k_local = 0: the one global threshold of rounds 3-5.
  * srcnn_fixup_local_stats: *k = margin * k_local in effect for the context's mode, *max_ratio = the largest
  * |v_kernel - v_reference| / thr(x) met on a flagged pixel since the context was created (synchronises the stream). */
