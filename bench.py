@@ -928,7 +928,7 @@ def worker(args):
                                    "per_pixel_threshold": dict(zip(("k", "largest_deviation_over_own_threshold_this_run"),
                                                                    (round(v, 4) for v in ctx.fixup_local_stats()))),
                                    # |v - r| / thr of the worst window any search has produced (not measured in this run): the searches
-                                   # climb on the k that keeps thr 1.73 x above the deviation and ask for 1.480 (CPU, 241 M evaluations;
+                                   # climb on the k that keeps thr 1.73 x above the deviation and ask for 1.480 - 1.540 (CPU, 241 M / 906 M evaluations;
                                    # GPU 1.480), a longer GPU climb 1.525), the library uses 1.6 (abs 2.44e-4): 0.55 of thr -- profiles/r06/fixup_adversarial_ratio.txt; the
                                    # worst of all is a window of LARGE local scale, where the cap delta binds: 7.93e-4 / 1.376e-3 (round 5's GPU search)
                                    "largest_deviation_any_search_found_over_threshold": 0.577,

@@ -143,12 +143,12 @@ constexpr float kFixMargin = 4.f;
 // (profiles/r06/README.md, "the per-pixel threshold"): the noise has a part that does not shrink with S1 -- with abs = 6.1e-5 the
 // windows of small local scale ask for k = 2.4, with 2.44e-4 for 1.48 -- and among the pairs that keep
 //   (R1) thr >= 1.73 x the deviation of EVERY window an adversarial search has produced (the factor the global delta keeps over the
-//        worst of them), the searches climbing on exactly that quantity: 241 M point evaluations on the CPU models
-//        (fixup_adversarial_ratio.txt: k >= 1.480; random models <= 1.05), 5.2 M window evaluations on the kernel itself in two
+//        worst of them), the searches climbing on exactly that quantity: 241 M and, from another seed, 906 M point evaluations on the CPU models
+//        (fixup_adversarial_ratio.txt: k >= 1.480, _long.txt: 1.540; random models <= 1.05), 5.2 M window evaluations on the kernel itself in two
 //        independent climbs (adversarial_gpu_ratio.txt: 1.480, adversarial_gpu_ratio_long.txt: 1.525; split-f16 kernel: 2.023 both), and
 //   (R2) thr >= 2.5 x the largest deviation on content (it then stays below 0.4 thr, short of the 1/2 at which the device-side net
 //        redoes a launch): 1.485 (sparse bright strokes on a dark ground; split-f16 kernel: 1.777),
-// abs = 16 * 2^-24 * 256 = 2.44e-4 is the cheapest on ordinary content.  k = 1.6 / 2.15 keep 5-6 % over the largest of those figures.
+// abs = 16 * 2^-24 * 256 = 2.44e-4 is the cheapest on ordinary content.  k = 1.6 / 2.15 keep 4-6 % over the largest of those figures.
 constexpr float kFixAbsTerm = 4.f * 256.f / 16777216.f;
 constexpr float kFixAbsLocal = 16.f * 256.f / 16777216.f;
 constexpr float kFixLocal = 0.4f;

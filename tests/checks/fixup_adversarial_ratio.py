@@ -14,7 +14,7 @@ pixel's receptive field ON THAT QUANTITY (a window may win by a large deviation 
 rounds 4-5 found -- for the shipped model and for the random model family of tests/checks/soak_models.py.
 tests/checks/fixup_local_scale.py SAMPLES the same quantity over content.
 
-Writes profiles/r06/fixup_adversarial_ratio<suffix>.txt and (no suffix) tests/golden/adversarial_windows_ratio.npz.
+Writes profiles/r06/fixup_adversarial_ratio<suffix>.txt and tests/golden/adversarial_windows_ratio<suffix>.npz.
 usage: fixup_adversarial_ratio.py [restarts_shipped=60000] [restarts_per_random_model=3000] [n_models=24] [seed] [suffix] [abs term]"""
 import sys
 import time
@@ -115,8 +115,8 @@ def main():
         fixture.update(random_blobs=np.stack(blobs), random_windows=np.stack(rw), random_kappa=np.stack(rr))
     log(f"# largest k needed: shipped {worst['shipped']:.3f}, random models {max([v for k, v in worst.items() if k != 'shipped'] or [0]):.3f};"
         f" {ev_total / 1e6:.0f} M point evaluations in total")
-    if not suffix:
-        np.savez_compressed(ROOT / "tests" / "golden" / "adversarial_windows_ratio.npz", **fixture)
+    # (a suffixed run -- another seed, more restarts -- keeps its windows beside the main fixture: tests/test_adversarial.py scores both)
+    np.savez_compressed(ROOT / "tests" / "golden" / f"adversarial_windows_ratio{suffix}.npz", **fixture)
     (out_dir / f"fixup_adversarial_ratio{suffix}.txt").write_text("\n".join(lines) + "\n")
 
 
