@@ -104,7 +104,7 @@ def bind_forward(cdll):
     cdll.srcnn_oracle_forward_y.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, _f32p, _f32p]
 
     def forward(src, blob):
-        return _forward(cdll.srcnn_oracle_forward_y, src, blob)[0]
+        return forward_y_once(src, blob, cdll.srcnn_oracle_forward_y)[0]      # timed only (bench.py): one run
     return forward
 
 
@@ -251,6 +251,15 @@ def _forward(fn, src, blob):
 def forward_y(src, blob):
     """Whole conv path (Convolution99x11 + Convolution55) -> (u8, f32 pre-clamp)."""
     return _forward(lib().srcnn_oracle_forward_y, src, blob)
+
+
+def forward_y_once(src, blob, fn=None):
+    """ONE run of the loops, whatever the host: what bench.py's cpu_baseline leg TIMES (the double runs of `_forward` are the
+    checker guarding itself, not part of the reference's cost)."""
+    src, ps = _u8(src)
+    blob, pw = _f32(blob)
+    assert blob.size == N_WEIGHTS
+    return _forward_once(fn or lib().srcnn_oracle_forward_y, src, ps, blob, pw)
 
 
 def gpuorder_forward_y(src, blob):

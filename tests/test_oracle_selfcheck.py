@@ -62,3 +62,22 @@ def test_small_hosts_and_large_planes_run_once():
     with mock.patch("os.cpu_count", return_value=8), mock.patch.object(oracle, "_forward_once", counting):
         oracle.forward_y(src, blob)
     assert len(calls) == 1
+
+
+def test_the_timed_entry_point_runs_the_loops_once_on_any_host():
+    """bench.py's cpu_baseline leg times oracle.forward_y_once: ONE run of the loops even where forward_y asks twice (a host with
+    more than 32 CPUs) -- the checker's double runs must not halve the reported CPU baseline (they did for a while in round 6)."""
+    blob = S.load_weights()
+    src = np.random.default_rng(8).integers(0, 256, (16, 16), dtype=np.uint8)
+    real, calls = oracle._forward_once, []
+
+    def counting(fn, s, ps, b, pw):
+        calls.append(1)
+        return real(fn, s, ps, b, pw)
+
+    with mock.patch("os.cpu_count", return_value=256), mock.patch.object(oracle, "_forward_once", counting):
+        a = oracle.forward_y_once(src, blob)
+        assert len(calls) == 1
+        b = oracle.forward_y(src, blob)
+        assert len(calls) == 3
+    assert np.array_equal(a[0], b[0])
